@@ -1,0 +1,136 @@
+/* libscrabble_hip.so -- C-ABI of the MI355X (gfx950) kernels behind the ScrabbleGAN train step.
+ *
+ * The reference (UtkuKaradeniz/scrabble-gan) has no FFI of its own: every op below is a TensorFlow
+ * primitive it calls from Python.  Each entry point names the reference call site it replaces
+ * (paths under /root/reference/src).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless typed otherwise); nothing
+ *     is retained after the call; no allocation happens inside (scratch is passed in)
+ *   - `stream` is a hipStream_t; all work is asynchronous on it
+ *   - tensors are NHWC contiguous; kernels use the TF layouts: Conv2D [kh,kw,Cin,Cout],
+ *     Conv2DTranspose [kh,kw,Cout,Cin], Dense [in,out]
+ *   - return 0 on success, <0 on error (SG_ERR_*); never throws
+ *   - weight/bias gradient outputs ACCUMULATE (+=): the caller zeroes the flat gradient buffer once
+ *     per step, which is what lets D/S passes on several batches share one buffer
+ */
+#ifndef SCRABBLE_HIP_H
+#define SCRABBLE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK 0
+#define SG_ERR_ARG (-1)
+#define SG_ERR_LAUNCH (-2)
+#define SG_ERR_UNSUPPORTED (-3)
+
+/* flags */
+#define SG_RELU_IN 1   /* max(x,0) applied to the activation operand while it is loaded        */
+#define SG_ACCUM 2     /* out += result                                                          */
+#define SG_RELU_OUT 4  /* max(.,0) applied to the result                                          */
+#define SG_TANH_OUT 8  /* tanh applied to the result (Cout == 1 path)                             */
+
+/* ---- convolutions: layers.Conv2D stride 1 (bigacgan/resnet_ops.py:65,98,103,109;
+ *      net_architecture.py:28-49,283; arch_ops.py:38-65 1x1) ------------------------------- */
+/* y = conv(relu?(x), w) + bias + bias2 ; x [B,H,W,Cin], y [B,Ho,Wo,Cout]; pad_same: 1 SAME, 0 VALID */
+int sg_conv2d_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y,
+                  int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+/* dx = conv_data_grad(dy, w) ; result zeroed where mask <= 0 (mask has dx's shape; ReLU backward);
+ * SG_ACCUM adds the previous dx AFTER masking (sum of the main and shortcut branches) */
+int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+/* dw += conv_weight_grad(relu?(x), dy) */
+int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
+                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+
+/* ---- layers.Conv2DTranspose(padding='same', strides=(sh,sw)) (resnet_ops.py:57,69) ------- */
+/* x [B,H,W,Cin] -> y [B,sh*H,sw*W,Cout]; k=3,s=2: y[2i+k] += x[i] w[k] cropped to 2n; bias everywhere */
+int sg_conv2d_transpose_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y,
+                            int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream);
+int sg_conv2d_transpose_bwd_data(const float* dy, const float* w, const float* mask, float* dx,
+                                 int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream);
+int sg_conv2d_transpose_bwd_weight(const float* x, const float* dy, float* dw,
+                                   int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream);
+
+/* db[n] += sum_m dy[m,n]  (bias gradient of any of the above; M = B*Ho*Wo rows) */
+int sg_bias_grad(const float* dy, float* db, long M, int N, void* stream);
+
+/* ---- pooling / elementwise ------------------------------------------------------------------- */
+/* out = avgpool2x2(a) + avgpool2x2(b) (b may be null): tf.nn.pool AVG SAME s2 + `net += shortcut`
+ * (resnet_ops.py:105-114) */
+int sg_avgpool2_add_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C, void* stream);
+int sg_avgpool2_bwd(const float* dout, float* dx, int B, int H, int W, int C, void* stream);   /* H,W of dx */
+int sg_add(const float* a, const float* b, float* out, long n, void* stream);
+int sg_relu_mask(const float* dy, const float* ref, float* dx, long n, void* stream);          /* dx = ref>0 ? dy : 0 */
+int sg_tanh_bwd(const float* y, const float* dy, float* dx, long n, void* stream);             /* net_architecture.py:289 */
+/* layers.MaxPool2D(pool_size=(ph,pw)) (arch_ops.py:47,58; net_architecture.py:29,32,38,47) */
+int sg_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, int ph, int pw, void* stream);
+int sg_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, int ph, int pw, int accum, void* stream);
+/* tf.nn.relu + GlobalAveragePooling2D (net_architecture.py:249-250,340-341,399-400) */
+int sg_gap_fwd(const float* x, float* out, int B, int HW, int C, int relu, void* stream);
+int sg_gap_bwd(const float* dout, const float* x, float* dx, int B, int HW, int C, int relu, void* stream);
+/* NonLocalBlock residual `sigma * attn_g + input` (arch_ops.py:67) and its pieces */
+int sg_scale_add(const float* o, const float* x, const float* sigma, float* out, long n, void* stream);
+int sg_scale(const float* a, const float* s, float* out, long n, void* stream);
+int sg_dot_accum(const float* a, const float* b, float* out, long n, void* stream);            /* out[0] += a.b */
+int sg_rowscale(const float* x, const float* s, float* out, long rows, int rowlen, void* stream);
+
+/* ---- Dense layers (resnet_ops.py:18,24; net_architecture.py:55,251,342,401) ---------------- */
+/* C = alpha*op(A)*op(B) + beta*C (+bias[n]); op(A) is MxK, op(B) is KxN; row-major with leading dims */
+int sg_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
+            int transA, int transB, float alpha, float beta, void* stream);
+
+/* ---- BatchNormalization / ConditionalBatchNorm (resnet_ops.py:13-28; net_architecture.py:42,46,281) */
+long sg_bn_stats_workspace_floats(long M, int C);
+/* sums[0:C] = sum x, sums[C:2C] = sum x^2 over the M rows (fp64; all-reduce these for SyncBN) */
+int sg_bn_stats_sums(const float* x, long M, int C, float* workspace, double* sums, void* stream);
+int sg_bn_stats_finalize(const double* sums, double count, float* mean, float* var, int C, void* stream);
+/* y = (x-mean)*rsqrt(var+eps)*gamma[b*gstride+c] + beta[b*gstride+c] (+ReLU); gstride=C: per-sample (CBN), 0: per-channel */
+int sg_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, int gstride,
+                float* y, int B, int HW, int C, float eps, int relu, void* stream);
+/* dgamma/dbeta [B,C] += per-sample sums (caller zeroes); chan (fp64 [4C]): sum dxhat, sum dxhat*xhat, sum_b dgamma, sum_b dbeta */
+int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* var, const float* gamma,
+                     int gstride, float* dgamma, float* dbeta, double* chan, int B, int HW, int C, float eps, int relu, void* stream);
+int sg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* var, const float* gamma,
+                    int gstride, const double* chan, double count, float* dx, int B, int HW, int C, float eps, int relu,
+                    int use_stats, void* stream);
+int sg_bn_update_moving(float* mm, float* mv, const float* mean, const float* var, double count, float momentum, int C, void* stream);
+
+/* ---- SpatialEmbedding filter bank + z0 contraction + seed layout (arch_ops.py:77-95;
+ *      net_architecture.py:229-231,259-271).  z [B,128] (z0 = z[:, :32]); y int32 [B,L];
+ *      table [vocab,32,8192]; seed [B,4,4L,512] ------------------------------------------------ */
+int sg_filterbank_fwd(const float* z, const int* y, const float* table, float* seed, int B, int L, int vocab, void* stream);
+int sg_filterbank_bwd(const float* z, const int* y, const float* table, const float* dseed, float* dtable, float* dz,
+                      int B, int L, int vocab, void* stream);
+
+/* ---- NonLocalBlock attention core (arch_ops.py:51-52,61): out = softmax(theta phi^T) g ------ */
+int sg_attention_fwd(const float* theta, const float* phi, const float* g, float* out, float* lse,
+                     int B, int Nq, int Nk, int dk, int dv, void* stream);
+int sg_attention_bwd(const float* theta, const float* phi, const float* g, const float* out, const float* lse, const float* dout,
+                     float* dtheta, float* dphi, float* dg, float* delta_scratch, int B, int Nq, int Nk, int dk, int dv, void* stream);
+
+/* ---- recognizer tail: softmax + K.ctc_batch_cost (net_architecture.py:55-64) ----------------
+ * logits [B,T,C] (pre-softmax Dense output), labels int32 [B,label_stride], blank = C-1.
+ * loss [B]; dlogits [B,T,C] = d loss_b / d logits_b, or null for forward only */
+int sg_softmax_ctc(const float* logits, const int* labels, int label_stride, float* loss, float* dlogits,
+                   int B, int T, int C, int input_length, int label_length, void* stream);
+
+/* ---- losses + gradient balancing + statistics (net_loss.py:4-54; data_utils.py:418-442,476-490) */
+/* mode 0 hinge, 1 not_saturating.  sums: fp64 [12] (all-reduce across ranks between the two calls) */
+int sg_loss_sums(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, const float* r_f,
+                 const float* r_r, int B, int mode, double* sums, void* stream);
+int sg_loss_grads(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, const float* r_f,
+                  int B, int mode, int balance, float alpha, const double* sums, float* scalars16, float* gD_r, float* gD_f,
+                  float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, void* stream);
+
+/* ---- optimizers (main.py:27-33; Keras Adam / RMSprop) and spectral_norm (arch_ops.py:98-126) */
+int sg_adam_update(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta_1, float beta_2, float eps, void* stream);
+int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream);
+long sg_spectral_norm_workspace_floats(int K, int N);
+int sg_spectral_norm(const float* w, const float* u, float* out, float* workspace, int K, int N, int power_iteration, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

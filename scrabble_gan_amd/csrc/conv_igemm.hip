@@ -1,0 +1,459 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// One kernel serves Conv2D forward, Conv2D data-grad, Conv2DTranspose forward (one launch per
+// output parity class) and Conv2DTranspose data-grad: see the tap-list formulation in sg_conv.h.
+//   A (im2col rows)  : gathered from NHWC global memory as float4 along channels, transposed into
+//                      LDS as As[k][m] (row stride BM+1 -> conflict-free b32 writes and reads)
+//   B (filter slice) : Bs[k][n]; either a straight float4 copy ([K,N] row-major weights) or the
+//                      same transposing loader as A when the weights are stored [N][K]
+//   MFMA             : 32x32x2 f32, lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]
+//   pipeline         : double-buffered LDS, next k-tile prefetched into registers under the MFMAs,
+//                      one barrier per k-tile; 2 workgroups (8 waves) resident per CU
+//   epilogue         : bias(+bias2), ReLU-backward mask, accumulate, ReLU, straight from the
+//                      accumulators (lanes 0-31 of a register write one 128-byte row segment)
+#include "sg_conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SG_BK 32
+
+__device__ __forceinline__ int sg_xcd_remap(int orig, int nwg) {
+  // bijective XCD-aware remap: blocks b and b+8 share an XCD (speed only, never correctness)
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+template <int BM, int BN, int WM, int WN, bool B_NK>
+__global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmArgs p) {
+  constexpr int BK = SG_BK;
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int LDA = BM + 1;
+  constexpr int LDB = B_NK ? BN + 1 : BN;
+  constexpr int A_P = BM * 8 / NT;          // float4 loads of A per thread per k-tile
+  constexpr int BKN_RPP = NT / (BN / 4);    // B rows covered per pass ([K,N] loader)
+  constexpr int BKN_P = BK / BKN_RPP;
+  constexpr int BNK_P = BN * 8 / NT;        // [N,K] loader passes
+  constexpr int B_P = B_NK ? BNK_P : BKN_P;
+  static_assert(A_P >= 1 && B_P >= 1, "tile/thread mismatch");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int M = p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const int wg = sg_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (wg / n_tiles) * BM;
+  const int n0 = (wg % n_tiles) * BN;
+
+  const int kchunks = (p.Ca + BK - 1) / BK;
+  const int KT = p.ntaps * kchunks;
+  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
+
+  // ---- per-thread A rows (fixed for the whole K loop) ----
+  const int kc = tid & 7;
+  int a_y[A_P], a_x[A_P], a_pix[A_P];
+  bool a_ok[A_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int r = (tid >> 3) + i * (NT / 8);
+    const int m = m0 + r;
+    a_ok[i] = m < M;
+    const int mm = a_ok[i] ? m : 0;
+    const int b = mm / HW;
+    const int rem = mm - b * HW;
+    const int yg = rem / p.Wg;
+    const int xg = rem - yg * p.Wg;
+    a_y[i] = yg * p.a_sy;
+    a_x[i] = xg * p.a_sx;
+    a_pix[i] = b * p.Ha * p.Wa;
+  }
+
+  float4 a_reg[A_P];
+  float4 b_reg[B_P];
+
+  auto load_tile = [&](int kt) {
+    const int t = kt / kchunks;
+    const int c0 = (kt - t * kchunks) * BK;
+    const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+    const float* wt = p.w + p.taps[t].w_off;
+    const int ca = c0 + 4 * kc;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa && ca < p.Ca;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(p.a + (size_t)(a_pix[i] + iy * p.Wa + ix) * p.Ca + ca);
+      a_reg[i] = v;
+    }
+    if (B_NK) {
+#pragma unroll
+      for (int i = 0; i < B_P; ++i) {
+        const int n = n0 + (tid >> 3) + i * (NT / 8);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.N && ca < p.Ca) v = *reinterpret_cast<const float4*>(wt + (size_t)n * p.ldw + ca);
+        b_reg[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_P; ++i) {
+        const int k = tid / (BN / 4) + i * BKN_RPP;
+        const int n = n0 + 4 * (tid % (BN / 4));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + k < p.Ca && n < p.N) v = *reinterpret_cast<const float4*>(wt + (size_t)(c0 + k) * p.ldw + n);
+        b_reg[i] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* as = As + buf * BK * LDA;
+    float* bs = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int r = (tid >> 3) + i * (NT / 8);
+      float4 v = a_reg[i];
+      if (relu_in) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      as[(4 * kc + 0) * LDA + r] = v.x;
+      as[(4 * kc + 1) * LDA + r] = v.y;
+      as[(4 * kc + 2) * LDA + r] = v.z;
+      as[(4 * kc + 3) * LDA + r] = v.w;
+    }
+    if (B_NK) {
+#pragma unroll
+      for (int i = 0; i < B_P; ++i) {
+        const int r = (tid >> 3) + i * (NT / 8);
+        const float4 v = b_reg[i];
+        bs[(4 * kc + 0) * LDB + r] = v.x;
+        bs[(4 * kc + 1) * LDB + r] = v.y;
+        bs[(4 * kc + 2) * LDB + r] = v.z;
+        bs[(4 * kc + 3) * LDB + r] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_P; ++i) {
+        const int k = tid / (BN / 4) + i * BKN_RPP;
+        const int nn = 4 * (tid % (BN / 4));
+        *reinterpret_cast<float4*>(bs + k * LDB + nn) = b_reg[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_col = wm * (BM / WM) + (lane & 31);
+  const int b_col = wn * (BN / WN) + (lane & 31);
+  const int khalf = lane >> 5;
+
+  if (KT > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const float* as = As + buf * BK * LDA + khalf * LDA + a_col;
+    const float* bs = Bs + buf * BK * LDB + khalf * LDB + b_col;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = as[kk * 2 * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = bs[kk * 2 * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const bool accum = (p.flags & SG_ACCUM) != 0;
+  const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    float bsum = 0.f;
+    if (p.bias) bsum += p.bias[n];
+    if (p.bias2) bsum += p.bias2[n];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const int b = m / HW;
+        const int rem = m - b * HW;
+        const int yg = rem / p.Wg;
+        const int xg = rem - yg * p.Wg;
+        const size_t idx =
+            ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
+        float v = acc[i][j][r] + bsum;
+        if (p.mask && p.mask[idx] <= 0.f) v = 0.f;
+        if (accum) v += p.out[idx];
+        if (relu_out) v = fmaxf(v, 0.f);
+        p.out[idx] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
+  const long M = (long)a.Bn * a.Hg * a.Wg;
+  const int grid = sg_cdiv(M, BM) * sg_cdiv(a.N, BN);
+  if (grid <= 0) return SG_OK;
+  if (b_nk)
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+  else
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+  return sg_launch_status();
+}
+
+int sg_launch_igemm(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
+  if ((a.Ca & 3) || (a.ldw & 3) || (!b_nk && (a.N & 3))) return SG_ERR_ARG;
+  if (a.ntaps < 0 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
+  if ((long)a.Bn * a.Ha * a.Wa * a.Ca >= (1L << 31) || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31))
+    return SG_ERR_ARG;  // 32-bit pixel indexing inside the kernel
+  if (a.N > 64) return launch_cfg<128, 128, 2, 2>(a, b_nk, s);
+  if (a.N > 32) return launch_cfg<128, 64, 2, 2>(a, b_nk, s);
+  return launch_cfg<128, 32, 4, 1>(a, b_nk, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// thin convolutions (Cin == 1 or Cout == 1): HBM-bound direct kernels, no matrix cores
+// ------------------------------------------------------------------------------------------
+// expand: out[m, c] = sum_t a1[pix(m)+tap_t] * w_t[c] + bias[c]      (a has ONE channel)
+__global__ __launch_bounds__(256) void sg_thin_expand_kernel(const SgThinArgs p) {
+  const int cq = p.C >> 2;  // float4 groups per pixel; divides 256
+  const long M = (long)p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long gsz = (long)gridDim.x * blockDim.x;
+  const int c = 4 * (int)(gtid % cq);
+  float4 wv[SG_MAX_TAPS];
+#pragma unroll
+  for (int t = 0; t < SG_MAX_TAPS; ++t)
+    wv[t] = t < p.ntaps ? *reinterpret_cast<const float4*>(p.w + p.taps[t].w_off + c)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + c);
+  const bool relu_in = p.flags & SG_RELU_IN, accum = p.flags & SG_ACCUM, relu_out = p.flags & SG_RELU_OUT;
+  for (long e = gtid; e < M * cq; e += gsz) {
+    const long m = e / cq;
+    const int b = (int)(m / HW);
+    const int rem = (int)(m - (long)b * HW);
+    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    float4 o = bv;
+#pragma unroll
+    for (int t = 0; t < SG_MAX_TAPS; ++t) {
+      if (t < p.ntaps) {
+        const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;
+        float a = 0.f;
+        if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
+        if (relu_in) a = fmaxf(a, 0.f);
+        o.x += a * wv[t].x; o.y += a * wv[t].y; o.z += a * wv[t].z; o.w += a * wv[t].w;
+      }
+    }
+    float* op = p.out + (size_t)m * p.C + c;
+    if (p.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(p.mask + (size_t)m * p.C + c);
+      if (mk.x <= 0.f) o.x = 0.f;
+      if (mk.y <= 0.f) o.y = 0.f;
+      if (mk.z <= 0.f) o.z = 0.f;
+      if (mk.w <= 0.f) o.w = 0.f;
+    }
+    if (accum) {
+      const float4 pv = *reinterpret_cast<const float4*>(op);
+      o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+    }
+    if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(op) = o;
+  }
+}
+
+// contract: out[m] = sum_t sum_c aC[pix(m)+tap_t, c] * w_t[c] + bias[0]   (out has ONE channel)
+// 16 lanes per pixel, float4 of channels per lane, 4-step shuffle reduction.
+__global__ __launch_bounds__(256) void sg_thin_contract_kernel(const SgThinArgs p) {
+  const long M = (long)p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const int sub = threadIdx.x & 15;
+  const long pix0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const long pstride = ((long)gridDim.x * blockDim.x) >> 4;
+  const bool relu_in = p.flags & SG_RELU_IN, accum = p.flags & SG_ACCUM, tanh_out = p.flags & SG_TANH_OUT;
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  const long Mpad = (M + 3) / 4 * 4;  // keep all 64 lanes in the shuffles
+  for (long m = pix0; m < Mpad; m += pstride) {
+    const bool live = m < M;
+    const long mm = live ? m : 0;
+    const int b = (int)(mm / HW);
+    const int rem = (int)(mm - (long)b * HW);
+    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    float s = 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;
+      if (!(iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa)) continue;
+      const float* ap = p.a + (((size_t)b * p.Ha + iy) * p.Wa + ix) * p.C;
+      const float* wp = p.w + p.taps[t].w_off;
+      for (int c = 4 * sub; c < p.C; c += 64) {
+        float4 a = *reinterpret_cast<const float4*>(ap + c);
+        const float4 w = *reinterpret_cast<const float4*>(wp + c);
+        if (relu_in) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        s += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (live && sub == 0) {
+      float v = s + bias;
+      if (p.mask && p.mask[m] <= 0.f) v = 0.f;
+      if (accum) v += p.out[m];
+      if (tanh_out) v = tanhf(v);
+      p.out[m] = v;
+    }
+  }
+}
+
+static int launch_thin(const SgThinArgs& a, bool expand, hipStream_t s) {
+  const long M = (long)a.Bn * a.Hg * a.Wg;
+  if (M <= 0) return SG_OK;
+  if (a.C & 3) return SG_ERR_ARG;
+  if (expand) {
+    if (256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sg_thin_expand_kernel, dim3(sg_grid_for(M * (a.C >> 2), 256)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(sg_thin_contract_kernel, dim3(sg_grid_for(M * 16, 256)), dim3(256), 0, s, a);
+  }
+  return sg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI entry points (include/scrabble_hip.h)
+// ------------------------------------------------------------------------------------------
+static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+extern "C" int sg_conv2d_fwd(const float* x, const float* w, const float* bias, const float* bias2,
+                             float* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                             int pad_same, int flags, void* stream) {
+  if (!x || !w || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1 || Cout == 1) {
+    SgThinArgs a{};
+    a.a = x; a.w = w; a.out = y; a.bias = bias; a.mask = nullptr;
+    a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.flags = flags; a.ntaps = kh * kw;
+    if (bias2) return SG_ERR_UNSUPPORTED;
+    a.C = (Cin == 1) ? Cout : Cin;
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * a.C};
+    return launch_thin(a, Cin == 1, s);
+  }
+  SgIgemmArgs a{};
+  a.a = x; a.w = w; a.out = y; a.bias = bias; a.bias2 = bias2; a.mask = nullptr;
+  a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
+  a.ntaps = kh * kw; a.ldw = Cout; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx)
+      a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm(a, false, s);
+}
+
+// dx[b,i,j,ci] = sum_{ky,kx,co} dy[b, i+ph-ky, j+pw-kx, co] * w[ky,kx,ci,co]; optional ReLU mask / accumulate
+extern "C" int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx,
+                                  int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                  int pad_same, int flags, void* stream) {
+  if (!dy || !w || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1 || Cout == 1) {
+    SgThinArgs a{};
+    a.a = dy; a.w = w; a.out = dx; a.bias = nullptr; a.mask = mask;
+    a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Hg = H; a.Wg = W; a.flags = flags; a.ntaps = kh * kw;
+    a.C = (Cin == 1) ? Cout : Cin;
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * a.C};
+    return launch_thin(a, /*expand=*/Cout == 1, s);
+  }
+  SgIgemmArgs a{};
+  a.a = dy; a.w = w; a.out = dx; a.mask = mask;
+  a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.ldw = Cout; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx)
+      a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm(a, /*b_nk=*/true, s);
+}
+
+// Conv2DTranspose(padding='same'): x [B,H,W,Cin] -> y [B,sh*H,sw*W,Cout], w [kh,kw,Cout,Cin].
+// One launch per output parity class; a class without taps still writes its bias.
+extern "C" int sg_conv2d_transpose_fwd(const float* x, const float* w, const float* bias,
+                                       const float* bias2, float* y, int B, int H, int W, int Cin,
+                                       int Cout, int kh, int kw, int sh, int sw, int flags,
+                                       void* stream) {
+  if (!x || !w || !y || kh * kw > SG_MAX_TAPS || sh < 1 || sw < 1) return SG_ERR_ARG;
+  const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  for (int py = 0; py < sh; ++py)
+    for (int px = 0; px < sw; ++px) {
+      SgIgemmArgs a{};
+      a.a = x; a.w = w; a.out = y; a.bias = bias; a.bias2 = bias2;
+      a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+      a.Ho = sh * H; a.Wo = sw * W; a.N = Cout; a.o_sy = sh; a.o_sx = sw; a.o_oy = py; a.o_ox = px;
+      a.ldw = Cin; a.flags = flags; a.ntaps = 0;
+      for (int ky = 0; ky < kh; ++ky) {
+        if ((py + pbh - ky) % sh) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+          if ((px + pbw - kx) % sw) continue;
+          a.taps[a.ntaps++] =
+              SgTap{floordiv(py + pbh - ky, sh), floordiv(px + pbw - kx, sw), (ky * kw + kx) * Cin * Cout};
+        }
+      }
+      const int rc = sg_launch_igemm(a, /*b_nk=*/true, (hipStream_t)stream);
+      if (rc != SG_OK) return rc;
+    }
+  return SG_OK;
+}
+
+// dx[b,i,j,ci] = sum_{ky,kx,co} dy[b, sh*i+ky-pbh, sw*j+kx-pbw, co] * w[ky,kx,co,ci]
+extern "C" int sg_conv2d_transpose_bwd_data(const float* dy, const float* w, const float* mask,
+                                            float* dx, int B, int H, int W, int Cin, int Cout,
+                                            int kh, int kw, int sh, int sw, int flags, void* stream) {
+  if (!dy || !w || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  SgIgemmArgs a{};
+  a.a = dy; a.w = w; a.out = dx; a.mask = mask;
+  a.Bn = B; a.Ha = sh * H; a.Wa = sw * W; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = sh; a.a_sx = sw;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.ldw = Cin; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx)
+      a.taps[ky * kw + kx] = SgTap{ky - pbh, kx - pbw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm(a, /*b_nk=*/false, (hipStream_t)stream);
+}

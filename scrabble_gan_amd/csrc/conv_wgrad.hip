@@ -1,0 +1,291 @@
+// Weight-gradient contraction on the fp32 matrix cores: dW_t[c][n] += sum_m P_t[m][c] * Q[m][n].
+//
+// The reduction runs over base-grid pixels m, so both operands are already "k-major" in NHWC
+// memory: a k-tile of 32 pixels x 128 channels is a straight float4 copy into Ps[k][c] / Qs[k][n]
+// (no transpose, conflict-free b32 fragment reads).  One workgroup owns (tap, c-tile, n-tile,
+// pixel-chunk); chunks of the same pixels are adjacent in the grid so that the 9 taps x c/n tiles
+// that re-read one activation slab run together and hit L2/Infinity Cache.  Partial sums are
+// added to dW with float atomics (one 128-byte row segment per half-wave: full atomic rate).
+#include "sg_conv.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BC, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64, 2) void sg_wgrad_kernel(const SgWgradArgs p) {
+  constexpr int BK = 32;
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
+  constexpr int P_RPP = NT / (BC / 4), P_P = BK / P_RPP;
+  constexpr int Q_RPP = NT / (BN / 4), Q_P = BK / Q_RPP;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * BC + 2 * BK * BN];
+  float* Ps = smem;
+  float* Qs = smem + 2 * BK * BC;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int c_tiles = (p.Cp + BC - 1) / BC, n_tiles = (p.Cq + BN - 1) / BN;
+  const int combos = p.ntaps * c_tiles * n_tiles;
+  const int combo = blockIdx.x % combos;
+  const int chunk = blockIdx.x / combos;
+  const int t = combo / (c_tiles * n_tiles);
+  const int c0 = ((combo / n_tiles) % c_tiles) * BC;
+  const int n0 = (combo % n_tiles) * BN;
+  const int M = p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const int m_begin = chunk * p.mchunk;
+  const int m_end = min(M, m_begin + p.mchunk);
+  const int KT = (m_end - m_begin + BK - 1) / BK;
+  const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
+
+  float4 p_reg[P_P], q_reg[Q_P];
+  const int pc = c0 + 4 * (tid % (BC / 4));
+  const int qn = n0 + 4 * (tid % (BN / 4));
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < P_P; ++i) {
+      const int m = m_begin + kt * BK + tid / (BC / 4) + i * P_RPP;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end && pc < p.Cp) {
+        const int b = m / HW, rem = m - b * HW;
+        const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+        const int iy = yg * p.p_sy + dy, ix = xg * p.p_sx + dx;
+        if (iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp)
+          v = *reinterpret_cast<const float4*>(p.p + ((size_t)(b * p.Hp + iy) * p.Wp + ix) * p.Cp + pc);
+      }
+      p_reg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_P; ++i) {
+      const int m = m_begin + kt * BK + tid / (BN / 4) + i * Q_RPP;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end && qn < p.Cq) {
+        const int b = m / HW, rem = m - b * HW;
+        const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+        v = *reinterpret_cast<const float4*>(
+            p.q + ((size_t)(b * p.Hq + yg * p.q_sy) * p.Wq + xg * p.q_sx) * p.Cq + qn);
+      }
+      q_reg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* ps = Ps + buf * BK * BC;
+    float* qs = Qs + buf * BK * BN;
+#pragma unroll
+    for (int i = 0; i < P_P; ++i) {
+      float4 v = p_reg[i];
+      if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(ps + (tid / (BC / 4) + i * P_RPP) * BC + 4 * (tid % (BC / 4))) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Q_P; ++i)
+      *reinterpret_cast<float4*>(qs + (tid / (BN / 4) + i * Q_RPP) * BN + 4 * (tid % (BN / 4))) = q_reg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int khalf = lane >> 5;
+  const int a_col = wm * (BC / WM) + (lane & 31);
+  const int b_col = wn * (BN / WN) + (lane & 31);
+
+  if (KT > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const float* ps = Ps + buf * BK * BC + khalf * BC + a_col;
+    const float* qs = Qs + buf * BK * BN + khalf * BN + b_col;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = ps[kk * 2 * BC + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = qs[kk * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* dwt = p.dw + p.taps[t].w_off;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    if (n >= p.Cq) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wm * (BC / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (c < p.Cp) atomicAdd(dwt + (size_t)c * p.Cq + n, acc[i][j][r]);
+      }
+  }
+}
+
+template <int BC, int BN, int WM, int WN>
+static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
+  const long M = (long)a.Bn * a.Hg * a.Wg;
+  const int combos = a.ntaps * sg_cdiv(a.Cp, BC) * sg_cdiv(a.Cq, BN);
+  if (combos <= 0 || M <= 0) return SG_OK;
+  long nchunks = (2048 + combos - 1) / combos;           // ~2048 workgroups: 8 per CU
+  const long max_chunks = (M + 255) / 256;               // at least 8 k-tiles per workgroup
+  if (nchunks > max_chunks) nchunks = max_chunks;
+  if (nchunks < 1) nchunks = 1;
+  long mchunk = (M + nchunks - 1) / nchunks;
+  mchunk = (mchunk + 31) / 32 * 32;
+  nchunks = (M + mchunk - 1) / mchunk;
+  a.mchunk = (int)mchunk;
+  hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN>), dim3((unsigned)(combos * nchunks)),
+                     dim3(WM * WN * 64), 0, s, a);
+  return sg_launch_status();
+}
+
+int sg_launch_wgrad(const SgWgradArgs& a, hipStream_t s) {
+  if ((a.Cp & 3) || (a.Cq & 3) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
+  if ((long)a.Bn * a.Hp * a.Wp * a.Cp >= (1L << 31) || (long)a.Bn * a.Hq * a.Wq * a.Cq >= (1L << 31))
+    return SG_ERR_ARG;
+  const bool c_small = a.Cp <= 64, n_small = a.Cq <= 64;
+  if (!c_small && !n_small) return launch_wgrad_cfg<128, 128, 2, 2>(a, s);
+  if (!c_small) return launch_wgrad_cfg<128, 64, 2, 2>(a, s);
+  if (!n_small) return launch_wgrad_cfg<64, 128, 2, 2>(a, s);
+  return launch_wgrad_cfg<64, 64, 2, 2>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// thin weight-grad: dW_t[c] += sum_m p1[pix(m)+tap_t] * Q[m, c]   (p1 has ONE channel)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, int pix_per_block) {
+  __shared__ float4 red[256];
+  const int cqn = p.C >> 2;            // float4 groups per pixel (divides 256)
+  const int lanes = 256 / cqn;         // pixels in flight per block
+  const int cq = threadIdx.x % cqn, pl = threadIdx.x / cqn;
+  const long M = (long)p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const long m_begin = (long)blockIdx.x * pix_per_block;
+  const long m_end = min(M, m_begin + pix_per_block);
+  const bool relu_in = p.flags & SG_RELU_IN;
+  const bool relu_q = p.flags & 16;    // internal: ReLU on the C-channel operand (Cout == 1 weight-grad)
+  float4 acc[SG_MAX_TAPS];
+#pragma unroll
+  for (int t = 0; t < SG_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long m = m_begin + pl; m < m_end; m += lanes) {
+    const int b = (int)(m / HW);
+    const int rem = (int)(m - (long)b * HW);
+    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    float4 q = *reinterpret_cast<const float4*>(p.w + (size_t)m * p.C + 4 * cq);
+    if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+#pragma unroll
+    for (int t = 0; t < SG_MAX_TAPS; ++t) {
+      if (t < p.ntaps) {
+        const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;
+        float a = 0.f;
+        if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
+        if (relu_in) a = fmaxf(a, 0.f);
+        acc[t].x += a * q.x; acc[t].y += a * q.y; acc[t].z += a * q.z; acc[t].w += a * q.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SG_MAX_TAPS; ++t) {
+    if (t >= p.ntaps) continue;   // block-uniform
+    red[threadIdx.x] = acc[t];
+    __syncthreads();
+    for (int s = lanes >> 1; s > 0; s >>= 1) {
+      if (pl < s) {
+        const float4 o = red[threadIdx.x + s * cqn];
+        float4 v = red[threadIdx.x];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        red[threadIdx.x] = v;
+      }
+      __syncthreads();
+    }
+    if (pl == 0) {
+      const float4 v = red[threadIdx.x];
+      float* d = p.out + p.taps[t].w_off + 4 * cq;
+      atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+    }
+    __syncthreads();
+  }
+}
+
+// p.a = one-channel operand [Bn,Ha,Wa], p.w = C-channel operand on the base grid [Bn,Hg,Wg,C],
+// p.out = dW (per tap a [C] vector at taps[t].w_off)
+static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
+  const long M = (long)a.Bn * a.Hg * a.Wg;
+  if (M <= 0) return SG_OK;
+  if ((a.C & 3) || 256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
+  int ppb = 2048;
+  const int grid = sg_cdiv(M, ppb);
+  hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), 0, s, a, ppb);
+  return sg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI entry points
+// ------------------------------------------------------------------------------------------
+extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W,
+                                    int Cin, int Cout, int kh, int kw, int pad_same, int flags,
+                                    void* stream) {
+  if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 1) {  // dW[t, co] = sum_m relu?(x)[pix+tap] * dy[m, co]
+    SgThinArgs a{};
+    a.a = x; a.w = dy; a.out = dw; a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.C = Cout;
+    a.ntaps = kh * kw; a.flags = flags;
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cout};
+    return launch_thin_wgrad(a, s);
+  }
+  if (Cout == 1) {  // dW[t, ci] = sum_m' x[m', ci] * dy[m' - tap]
+    SgThinArgs a{};
+    a.a = dy; a.w = x; a.out = dw; a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Hg = H; a.Wg = W; a.C = Cin;
+    a.ntaps = kh * kw; a.flags = (flags & SG_RELU_IN) ? 16 : 0;
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin};
+    return launch_thin_wgrad(a, s);
+  }
+  SgWgradArgs a{};
+  a.p = x; a.q = dy; a.dw = dw;
+  a.Bn = B; a.Hp = H; a.Wp = W; a.Cp = Cin; a.p_sy = 1; a.p_sx = 1;
+  a.Hq = Ho; a.Wq = Wo; a.Cq = Cout; a.q_sy = 1; a.q_sx = 1; a.Hg = Ho; a.Wg = Wo;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx)
+      a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_wgrad(a, s);
+}
+
+// dW[ky,kx,co,ci] += sum_{b,i,j} dy[b, sh*i+ky-pbh, sw*j+kx-pbw, co] * x[b,i,j,ci]
+extern "C" int sg_conv2d_transpose_bwd_weight(const float* x, const float* dy, float* dw, int B,
+                                              int H, int W, int Cin, int Cout, int kh, int kw,
+                                              int sh, int sw, int flags, void* stream) {
+  if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (flags & SG_RELU_IN) return SG_ERR_UNSUPPORTED;
+  const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  SgWgradArgs a{};
+  a.p = dy; a.q = x; a.dw = dw;
+  a.Bn = B; a.Hp = sh * H; a.Wp = sw * W; a.Cp = Cout; a.p_sy = sh; a.p_sx = sw;
+  a.Hq = H; a.Wq = W; a.Cq = Cin; a.q_sy = 1; a.q_sx = 1; a.Hg = H; a.Wg = W;
+  a.ntaps = kh * kw; a.flags = 0;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx)
+      a.taps[ky * kw + kx] = SgTap{ky - pbh, kx - pbw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_wgrad(a, (hipStream_t)stream);
+}

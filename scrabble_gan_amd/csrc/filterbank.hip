@@ -1,0 +1,87 @@
+// Per-character filter bank (SpatialEmbedding) fused with the z0 contraction and the seed layout.
+// Replaces tf.nn.embedding_lookup + tile + matmul + reshape/reshape/transpose of
+// /root/reference/src/bigacgan/arch_ops.py:89-90 and net_architecture.py:262-271 without
+// materialising the gathered [B,L,32,8192] tensor:
+//   seed[b, r, 4l+pw, q] = sum_k z0[b,k] * E[y[b,l], k, j],   j = pw*2048 + q*4 + r
+// One thread owns 4 consecutive j (one float4 of the table row = the 4 seed rows r of one (pw,q)),
+// so table reads are 16-byte coalesced and each of the 4 seed stores is coalesced across lanes.
+// The 54.5 MB table stays resident in the Infinity Cache across the B*L gathers.
+#include "sg_common.h"
+
+#define FB_K 32
+#define FB_J 8192
+
+__global__ __launch_bounds__(256) void k_filterbank_fwd(const float* z0, const int* y, const float* table, float* seed, int L, int vocab) {
+  __shared__ float zs[FB_K];
+  const int bl = blockIdx.y;            // b*L + l
+  const int b = bl / L, l = bl - b * L;
+  if (threadIdx.x < FB_K) zs[threadIdx.x] = z0[(size_t)b * 128 + threadIdx.x];   // z row stride 128: z0 = z[:, :32]
+  __syncthreads();
+  int cls = y[bl];
+  cls = cls < 0 ? 0 : (cls >= vocab ? vocab - 1 : cls);
+  const int j = 4 * (blockIdx.x * 256 + threadIdx.x);
+  const float* e = table + (size_t)cls * FB_K * FB_J + j;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int k = 0; k < FB_K; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(e + (size_t)k * FB_J);
+    const float z = zs[k];
+    acc.x += z * v.x; acc.y += z * v.y; acc.z += z * v.z; acc.w += z * v.w;
+  }
+  const int pw = j >> 11, q = (j & 2047) >> 2;
+  const int W4 = 4 * L;
+  const size_t base = ((size_t)b * 4 * W4 + 4 * l + pw) * 512 + q;     // r = 0
+  const size_t rs = (size_t)W4 * 512;
+  seed[base] = acc.x; seed[base + rs] = acc.y; seed[base + 2 * rs] = acc.z; seed[base + 3 * rs] = acc.w;
+}
+
+// dE[y[b,l],k,j] += z0[b,k]*dseed[...] (float atomics, 256 contiguous bytes per wave instruction)
+// dz[b,k]        += sum_j E[y[b,l],k,j]*dseed[...]
+__global__ __launch_bounds__(256) void k_filterbank_bwd(const float* z0, const int* y, const float* table, const float* dseed,
+                                                        float* dtable, float* dz, int L, int vocab) {
+  __shared__ float zs[FB_K];
+  __shared__ float red[4][FB_K];
+  const int bl = blockIdx.y;
+  const int b = bl / L, l = bl - b * L;
+  if (threadIdx.x < FB_K) zs[threadIdx.x] = z0[(size_t)b * 128 + threadIdx.x];
+  __syncthreads();
+  int cls = y[bl];
+  cls = cls < 0 ? 0 : (cls >= vocab ? vocab - 1 : cls);
+  const int j = 4 * (blockIdx.x * 256 + threadIdx.x);
+  const int pw = j >> 11, q = (j & 2047) >> 2;
+  const int W4 = 4 * L;
+  const size_t base = ((size_t)b * 4 * W4 + 4 * l + pw) * 512 + q;
+  const size_t rs = (size_t)W4 * 512;
+  const float4 d = make_float4(dseed[base], dseed[base + rs], dseed[base + 2 * rs], dseed[base + 3 * rs]);
+  const float* e = table + (size_t)cls * FB_K * FB_J + j;
+  float* de = dtable + (size_t)cls * FB_K * FB_J + j;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < FB_K; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(e + (size_t)k * FB_J);
+    const float z = zs[k];
+    float* dp = de + (size_t)k * FB_J;
+    atomicAdd(dp + 0, z * d.x); atomicAdd(dp + 1, z * d.y); atomicAdd(dp + 2, z * d.z); atomicAdd(dp + 3, z * d.w);
+    float s = v.x * d.x + v.y * d.y + v.z * d.z + v.w * d.w;
+    s = sg_wave_sum(s);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < FB_K)
+    atomicAdd(dz + (size_t)b * 128 + threadIdx.x,
+              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// z: [B,128] (only columns 0..31 are read: z0); seed: [B,4,4L,512]
+extern "C" int sg_filterbank_fwd(const float* z, const int* y, const float* table, float* seed, int B, int L, int vocab, void* stream) {
+  if (!z || !y || !table || !seed || B < 1 || L < 1) return SG_ERR_ARG;
+  hipLaunchKernelGGL(k_filterbank_fwd, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, z, y, table, seed, L, vocab);
+  return sg_launch_status();
+}
+
+// dtable += ..., dz[:, 0:32] += ...   (dz is the [B,128] gradient of z)
+extern "C" int sg_filterbank_bwd(const float* z, const int* y, const float* table, const float* dseed, float* dtable, float* dz,
+                                 int B, int L, int vocab, void* stream) {
+  if (!z || !y || !table || !dseed || !dtable || !dz || B < 1 || L < 1) return SG_ERR_ARG;
+  hipLaunchKernelGGL(k_filterbank_bwd, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, z, y, table, dseed, dtable, dz, L, vocab);
+  return sg_launch_status();
+}

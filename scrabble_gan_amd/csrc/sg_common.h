@@ -1,0 +1,49 @@
+// Shared device/host helpers for the gfx950 kernels of the ScrabbleGAN train step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SG_OK 0
+#define SG_ERR_ARG (-1)
+#define SG_ERR_LAUNCH (-2)
+#define SG_ERR_UNSUPPORTED (-3)
+
+#define SG_WAVE 64
+
+// flags shared by the conv entry points (include/scrabble_hip.h)
+#define SG_RELU_IN 1    // apply max(x,0) to the activation operand while loading it
+#define SG_ACCUM 2      // out += result instead of out = result
+#define SG_RELU_OUT 4   // apply max(.,0) to the result
+#define SG_TANH_OUT 8   // apply tanh to the result (thin Cout=1 path only)
+
+static inline int sg_launch_status() {
+  return hipGetLastError() == hipSuccess ? SG_OK : SG_ERR_LAUNCH;
+}
+
+static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+static inline int sg_grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float sg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ double sg_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,392 @@
+"""Tensor-level wrappers over the C-ABI (include/scrabble_hip.h).
+
+torch is used for device memory and the current HIP stream only; every arithmetic op below is a
+hand-written gfx950 kernel in libscrabble_hip.so.  All tensors are fp32, contiguous, NHWC, on the
+GPU.  Nothing here falls back to torch math: a missing library or a failed launch raises."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import call, lib
+
+RELU_IN, ACCUM, RELU_OUT, TANH_OUT = 1, 2, 4, 8
+BN_EPS = 1e-3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise ValueError("expected a contiguous fp32 CUDA tensor, got %s %s contiguous=%s"
+                             % (t.device, t.dtype, t.is_contiguous()))
+
+
+def _flags(relu_in=False, accum=False, relu_out=False, tanh_out=False) -> int:
+    return (RELU_IN if relu_in else 0) | (ACCUM if accum else 0) | (RELU_OUT if relu_out else 0) | (TANH_OUT if tanh_out else 0)
+
+
+def empty(*shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+# ---------------------------------------------------------------- convolutions
+def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,
+               out=None, accum=False):
+    _chk(x, w, bias, bias2, out)
+    B, H, W, Cin = x.shape
+    kh, kw, wc, Cout = w.shape
+    assert wc == Cin, (w.shape, x.shape)
+    Ho, Wo = (H, W) if same else (H - kh + 1, W - kw + 1)
+    if out is None:
+        out = empty(B, Ho, Wo, Cout, like=x)
+    call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+         _flags(relu_in, accum, relu_out, tanh_out), _stream())
+    return out
+
+
+def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=None, accum=False):
+    _chk(dy, w, mask, out)
+    B = dy.shape[0]
+    H, W = in_hw
+    kh, kw, Cin, Cout = w.shape
+    assert dy.shape[3] == Cout
+    if out is None:
+        out = empty(B, H, W, Cin, like=dy)
+    call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+         _flags(accum=accum), _stream())
+    return out
+
+
+def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False):
+    _chk(x, dy, dw)
+    B, H, W, Cin = x.shape
+    kh, kw, wc, Cout = dw.shape
+    assert wc == Cin and dy.shape[3] == Cout
+    call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
+
+
+def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
+    _chk(x, w, bias, bias2, out)
+    B, H, W, Cin = x.shape
+    kh, kw, Cout, wc = w.shape
+    assert wc == Cin
+    sh, sw = stride
+    if out is None:
+        out = empty(B, sh * H, sw * W, Cout, like=x)
+    call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+         _flags(accum=accum), _stream())
+    return out
+
+
+def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=False):
+    _chk(dy, w, mask, out)
+    kh, kw, Cout, Cin = w.shape
+    sh, sw = stride
+    B, Hs, Ws, _ = dy.shape
+    H, W = Hs // sh, Ws // sw
+    if out is None:
+        out = empty(B, H, W, Cin, like=dy)
+    call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+         _flags(accum=accum), _stream())
+    return out
+
+
+def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
+    _chk(x, dy, dw)
+    B, H, W, Cin = x.shape
+    kh, kw, Cout, wc = dw.shape
+    assert wc == Cin
+    sh, sw = stride
+    call("sg_conv2d_transpose_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, 0, _stream())
+
+
+def bias_grad(dy, db):
+    _chk(dy, db)
+    N = dy.shape[-1]
+    call("sg_bias_grad", _p(dy), _p(db), dy.numel() // N, N, _stream())
+
+
+# ---------------------------------------------------------------- pooling / elementwise
+def avgpool2_add_fwd(a, b=None):
+    _chk(a, b)
+    B, H, W, C = a.shape
+    out = empty(B, H // 2, W // 2, C, like=a)
+    call("sg_avgpool2_add_fwd", _p(a), _p(b), _p(out), B, H, W, C, _stream())
+    return out
+
+
+def avgpool2_bwd(dout):
+    _chk(dout)
+    B, Ho, Wo, C = dout.shape
+    dx = empty(B, 2 * Ho, 2 * Wo, C, like=dout)
+    call("sg_avgpool2_bwd", _p(dout), _p(dx), B, 2 * Ho, 2 * Wo, C, _stream())
+    return dx
+
+
+def add(a, b, out=None):
+    _chk(a, b, out)
+    assert a.shape == b.shape
+    if out is None:
+        out = torch.empty_like(a)
+    call("sg_add", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def relu_mask(dy, ref, out=None):
+    _chk(dy, ref, out)
+    if out is None:
+        out = torch.empty_like(dy)
+    call("sg_relu_mask", _p(dy), _p(ref), _p(out), dy.numel(), _stream())
+    return out
+
+
+def tanh_bwd(y, dy):
+    _chk(y, dy)
+    dx = torch.empty_like(dy)
+    call("sg_tanh_bwd", _p(y), _p(dy), _p(dx), dy.numel(), _stream())
+    return dx
+
+
+def maxpool_fwd(x, ph, pw):
+    _chk(x)
+    B, H, W, C = x.shape
+    y = empty(B, H // ph, W // pw, C, like=x)
+    idx = empty(B, H // ph, W // pw, C, like=x, dtype=torch.uint8)
+    call("sg_maxpool_fwd", _p(x), _p(y), idx.data_ptr(), B, H, W, C, ph, pw, _stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, ph, pw, out=None, accum=False):
+    _chk(dy, out)
+    B, Ho, Wo, C = dy.shape
+    if out is None:
+        out = empty(B, Ho * ph, Wo * pw, C, like=dy)
+    call("sg_maxpool_bwd", _p(dy), idx.data_ptr(), _p(out), B, Ho * ph, Wo * pw, C, ph, pw, int(accum), _stream())
+    return out
+
+
+def gap_fwd(x, relu=True):
+    _chk(x)
+    B, H, W, C = x.shape
+    out = empty(B, C, like=x)
+    call("sg_gap_fwd", _p(x), _p(out), B, H * W, C, int(relu), _stream())
+    return out
+
+
+def gap_bwd(dout, x, relu=True):
+    _chk(dout, x)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    call("sg_gap_bwd", _p(dout), _p(x), _p(dx), B, H * W, C, int(relu), _stream())
+    return dx
+
+
+def scale_add(o, x, sigma):
+    _chk(o, x, sigma)
+    out = torch.empty_like(x)
+    call("sg_scale_add", _p(o), _p(x), _p(sigma), _p(out), x.numel(), _stream())
+    return out
+
+
+def scale(a, s):
+    _chk(a, s)
+    out = torch.empty_like(a)
+    call("sg_scale", _p(a), _p(s), _p(out), a.numel(), _stream())
+    return out
+
+
+def dot_accum(a, b, out):
+    _chk(a, b, out)
+    call("sg_dot_accum", _p(a), _p(b), _p(out), a.numel(), _stream())
+
+
+def rowscale(x, s):
+    _chk(x, s)
+    out = torch.empty_like(x)
+    rows = s.numel()
+    call("sg_rowscale", _p(x), _p(s), _p(out), rows, x.numel() // rows, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- dense
+def gemm(A, B, M, N, K, lda, ldb, transA=False, transB=False, bias=None, out=None, ldc=None, alpha=1.0, beta=0.0):
+    _chk(A, B, bias, out)
+    if out is None:
+        out = empty(M, N, like=A)
+    ldc = N if ldc is None else ldc
+    call("sg_gemm", _p(A), _p(B), _p(out), _p(bias), M, N, K, lda, ldb, ldc, int(transA), int(transB), float(alpha), float(beta), _stream())
+    return out
+
+
+def dense_fwd(x2d, w, bias=None):
+    """x2d [M,K] @ w [K,N] (+bias)."""
+    M, K = x2d.shape
+    N = w.shape[1]
+    return gemm(x2d, w, M, N, K, K, N, bias=bias)
+
+
+def dense_bwd_input(dy2d, w):
+    """dy [M,N] @ w^T [N,K] -> [M,K]."""
+    M, N = dy2d.shape
+    K = w.shape[0]
+    return gemm(dy2d, w, M, K, N, N, N, transB=True)
+
+
+def dense_bwd_weight(x2d, dy2d, dw):
+    """dw [K,N] += x^T [K,M] @ dy [M,N]."""
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    gemm(x2d, dy2d, K, N, M, K, N, transA=True, out=dw, beta=1.0)
+
+
+# ---------------------------------------------------------------- batch norm
+def bn_stats_sums(x):
+    """fp64 [2C]: per-channel sum and sum of squares over all rows of x[..., C]."""
+    _chk(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = empty(lib().sg_bn_stats_workspace_floats(M, C), like=x)
+    sums = empty(2 * C, like=x, dtype=torch.float64)
+    call("sg_bn_stats_sums", _p(x), M, C, _p(ws), sums.data_ptr(), _stream())
+    return sums
+
+
+def bn_stats_finalize(sums, count, like):
+    C = sums.numel() // 2
+    mean, var = empty(C, like=like), empty(C, like=like)
+    call("sg_bn_stats_finalize", sums.data_ptr(), float(count), _p(mean), _p(var), C, _stream())
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, per_sample: bool, relu: bool, eps=BN_EPS):
+    _chk(x, mean, var, gamma, beta)
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    call("sg_bn_apply", _p(x), _p(mean), _p(var), _p(gamma), _p(beta), C if per_sample else 0, _p(y), B, H * W, C, eps, int(relu), _stream())
+    return y
+
+
+def bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample: bool, relu: bool, eps=BN_EPS):
+    """-> dgamma [B,C], dbeta [B,C] (per-sample sums), chan fp64 [4C]."""
+    _chk(dy, y, x, mean, var, gamma)
+    B, H, W, C = x.shape
+    dgamma = torch.zeros(B, C, device=x.device, dtype=torch.float32)
+    dbeta = torch.zeros(B, C, device=x.device, dtype=torch.float32)
+    chan = empty(4 * C, like=x, dtype=torch.float64)
+    call("sg_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0, _p(dgamma), _p(dbeta),
+         chan.data_ptr(), B, H * W, C, eps, int(relu), _stream())
+    return dgamma, dbeta, chan
+
+
+def bn_bwd_apply(dy, y, x, mean, var, gamma, per_sample: bool, chan, count, relu: bool, use_stats: bool, eps=BN_EPS):
+    _chk(dy, y, x, mean, var, gamma)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    call("sg_bn_bwd_apply", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0,
+         None if chan is None else chan.data_ptr(), float(count), _p(dx), B, H * W, C, eps, int(relu), int(use_stats), _stream())
+    return dx
+
+
+def bn_update_moving(mm, mv, mean, var, count, momentum=0.99):
+    _chk(mm, mv, mean, var)
+    call("sg_bn_update_moving", _p(mm), _p(mv), _p(mean), _p(var), float(count), momentum, mm.numel(), _stream())
+
+
+# ---------------------------------------------------------------- filter bank
+def filterbank_fwd(z, y, table):
+    _chk(z, table)
+    B, L = y.shape
+    assert y.dtype == torch.int32 and y.is_contiguous() and z.shape[1] == 128
+    assert table.shape[1] == 32 and table.shape[2] == 8192
+    seed = empty(B, 4, 4 * L, 512, like=z)
+    call("sg_filterbank_fwd", _p(z), y.data_ptr(), _p(table), _p(seed), B, L, table.shape[0], _stream())
+    return seed
+
+
+def filterbank_bwd(z, y, table, dseed, dtable, dz):
+    _chk(z, table, dseed, dtable, dz)
+    B, L = y.shape
+    call("sg_filterbank_bwd", _p(z), y.data_ptr(), _p(table), _p(dseed), _p(dtable), _p(dz), B, L, table.shape[0], _stream())
+
+
+# ---------------------------------------------------------------- attention
+def attention_fwd(theta, phi, g):
+    _chk(theta, phi, g)
+    B, Nq, dk = theta.shape
+    Nk, dv = g.shape[1], g.shape[2]
+    out = empty(B, Nq, dv, like=theta)
+    lse = empty(B, Nq, like=theta)
+    call("sg_attention_fwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), B, Nq, Nk, dk, dv, _stream())
+    return out, lse
+
+
+def attention_bwd(theta, phi, g, out, lse, dout):
+    _chk(theta, phi, g, out, lse, dout)
+    B, Nq, dk = theta.shape
+    Nk, dv = g.shape[1], g.shape[2]
+    dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+    delta = empty(B, Nq, like=theta)
+    call("sg_attention_bwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), _p(dout), _p(dtheta), _p(dphi), _p(dg), _p(delta),
+         B, Nq, Nk, dk, dv, _stream())
+    return dtheta, dphi, dg
+
+
+# ---------------------------------------------------------------- CTC
+def softmax_ctc(logits, labels, input_length, label_length, need_grad=True):
+    _chk(logits)
+    B, T, C = logits.shape
+    assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.shape[0] == B
+    loss = empty(B, like=logits)
+    dlogits = torch.empty_like(logits) if need_grad else None
+    call("sg_softmax_ctc", _p(logits), labels.data_ptr(), labels.shape[1], _p(loss), _p(dlogits), B, T, C, int(input_length),
+         int(label_length), _stream())
+    return loss, dlogits
+
+
+# ---------------------------------------------------------------- loss head
+def loss_sums(d_r, d_f, s_my, s_f, s_r, r_f, r_r, mode: int):
+    _chk(d_r, d_f, s_my, s_f, s_r, r_f, r_r)
+    sums = empty(12, like=d_r, dtype=torch.float64)
+    call("sg_loss_sums", _p(d_r), _p(d_f), _p(s_my), _p(s_f), _p(s_r), _p(r_f), _p(r_r), d_r.numel(), mode, sums.data_ptr(), _stream())
+    return sums
+
+
+def loss_grads(d_r, d_f, s_my, s_f, s_r, r_f, mode: int, balance: bool, alpha: float, sums):
+    B = d_r.numel()
+    scalars = empty(16, like=d_r)
+    outs = [empty(B, like=d_r) for _ in range(7)]
+    call("sg_loss_grads", _p(d_r), _p(d_f), _p(s_my), _p(s_f), _p(s_r), _p(r_f), B, mode, int(balance), float(alpha), sums.data_ptr(),
+         _p(scalars), *[_p(o) for o in outs], _stream())
+    return scalars, outs
+
+
+# ---------------------------------------------------------------- optimizers / spectral norm
+def adam_update(p, g, m, v, lr_t, beta_1, beta_2, eps=1e-7):
+    _chk(p, g, m, v)
+    call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
+
+
+def rmsprop_update(p, g, ms, lr, rho=0.9, eps=1e-7):
+    _chk(p, g, ms)
+    call("sg_rmsprop_update", _p(p), _p(g), _p(ms), p.numel(), float(lr), float(rho), float(eps), _stream())
+
+
+def spectral_norm(w, u, power_iteration=1):
+    _chk(w, u)
+    N = w.shape[-1]
+    K = w.numel() // N
+    out = torch.empty_like(w)
+    ws = empty(lib().sg_spectral_norm_workspace_floats(K, N), like=w)
+    call("sg_spectral_norm", _p(w), _p(u), _p(out), _p(ws), K, N, int(power_iteration), _stream())
+    return out

@@ -89,9 +89,11 @@ int sg_bn_stats_finalize(const double* sums, double count, float* mean, float* v
 /* y = (x-mean)*rsqrt(var+eps)*gamma[b*gstride+c] + beta[b*gstride+c] (+ReLU); gstride=C: per-sample (CBN), 0: per-channel */
 int sg_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta, int gstride,
                 float* y, int B, int HW, int C, float eps, int relu, void* stream);
-/* dgamma/dbeta [B,C] += per-sample sums (caller zeroes); chan (fp64 [4C]): sum dxhat, sum dxhat*xhat, sum_b dgamma, sum_b dbeta */
+/* dgamma/dbeta [B,C] += per-sample sums (caller zeroes); chan (fp64 [4C]): sum dxhat, sum dxhat*xhat, sum_b dgamma, sum_b dbeta;
+ * dgamma_c/dbeta_c [C] (nullable) += sum_b dgamma/dbeta: the gradients of a per-channel gamma/beta */
 int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* var, const float* gamma,
-                     int gstride, float* dgamma, float* dbeta, double* chan, int B, int HW, int C, float eps, int relu, void* stream);
+                     int gstride, float* dgamma, float* dbeta, double* chan, float* dgamma_c, float* dbeta_c, int B, int HW, int C,
+                     float eps, int relu, void* stream);
 int sg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* var, const float* gamma,
                     int gstride, const double* chan, double count, float* dx, int B, int HW, int C, float eps, int relu,
                     int use_stats, void* stream);

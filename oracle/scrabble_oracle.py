@@ -42,7 +42,7 @@ def conv2d(x: Tensor, w: Tensor, b: Optional[Tensor] = None, padding: str = "sam
     Cross-correlation; SAME pads (k-1)/2 on every side for odd k; VALID pads nothing."""
     kh, kw = w.shape[0], w.shape[1]
     pad = (kh // 2, kw // 2) if padding == "same" else (0, 0)
-    y = F.conv2d(_nchw(x), w.permute(3, 2, 0, 1), b, stride=1, padding=pad)
+    y = F.conv2d(_nchw(x).contiguous(), w.permute(3, 2, 0, 1).contiguous(), b, stride=1, padding=pad)
     return _nhwc(y)
 
 
@@ -61,7 +61,7 @@ def conv2d_transpose(x: Tensor, w: Tensor, b: Optional[Tensor], stride: Tuple[in
         else:
             pads.append(0)
             outp.append(s - 1 if k == 1 else 0)
-    y = F.conv_transpose2d(_nchw(x), w.permute(3, 2, 0, 1), None, stride=(sh, sw),
+    y = F.conv_transpose2d(_nchw(x).contiguous(), w.permute(3, 2, 0, 1).contiguous(), None, stride=(sh, sw),
                            padding=tuple(pads), output_padding=tuple(outp))
     y = y[:, :, : H * sh, : W * sw]
     if b is not None:

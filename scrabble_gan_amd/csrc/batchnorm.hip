@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* dy, const fl
 // per channel: s[0][c] = sum_b gamma[b,c]*dbeta[b,c] (= sum dx_hat), s[1][c] = sum_b gamma[b,c]*dgamma[b,c]
 // (= sum dx_hat*x_hat), s[2][c] = sum_b dgamma[b,c], s[3][c] = sum_b dbeta[b,c]   (fp64)
 __global__ __launch_bounds__(256) void k_bn_bwd_chan(const float* dgamma, const float* dbeta, const float* gamma, int gstride,
-                                                     int B, int C, double* s) {
+                                                     int B, int C, double* s, float* dgamma_c, float* dbeta_c) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_chan(const float* dgamma, const 
     a0 += g * db; a1 += g * dg; a2 += dg; a3 += db;
   }
   s[c] = a0; s[C + c] = a1; s[2 * C + c] = a2; s[3 * C + c] = a3;
+  if (dgamma_c) dgamma_c[c] += (float)a2;     // per-channel affine (plain BatchNormalization): grads accumulate
+  if (dbeta_c) dbeta_c[c] += (float)a3;
 }
 
 // backward pass 2: dx = rstd * (dz*gamma - s0/n - x_hat * s1/n); use_stats=0 -> inference-mode BN (dx = dz*gamma*rstd)
@@ -212,13 +214,14 @@ extern "C" int sg_bn_apply(const float* x, const float* mean, const float* var, 
 
 // dgamma/dbeta are [B,C] and must be zeroed by the caller; chan (fp64 [4*C]) receives the per-channel sums
 extern "C" int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* var,
-                                const float* gamma, int gstride, float* dgamma, float* dbeta, double* chan, int B, int HW,
-                                int C, float eps, int relu, void* stream) {
+                                const float* gamma, int gstride, float* dgamma, float* dbeta, double* chan, float* dgamma_c,
+                                float* dbeta_c, int B, int HW, int C, float eps, int relu, void* stream) {
   if (!dy || !x || !mean || !var || !gamma || !dgamma || !dbeta || !chan || !chan_ok(C) || (relu && !y)) return SG_ERR_ARG;
   const int rpb = 512;
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(sg_cdiv(HW, rpb), B), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, var, dgamma,
                      dbeta, HW, C, eps, relu, rpb);
-  hipLaunchKernelGGL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan);
+  hipLaunchKernelGGL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan,
+                     dgamma_c, dbeta_c);
   return sg_launch_status();
 }
 

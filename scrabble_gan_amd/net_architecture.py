@@ -1,0 +1,501 @@
+"""Model factories with the reference's names and signatures
+(/root/reference/src/bigacgan/net_architecture.py): make_recognizer :9-79, make_my_recognizer :82-179,
+make_generator :182-296, make_discriminator :299-355, make_style_promoter :358-414, make_gan :531-561,
+get_in_out_channels_gen :565-573, get_in_out_channels_disc :576-586.
+
+The returned objects duck-type the subset of tf.keras.Model the reference's callers touch
+(`model(inputs, training=...)`, `.trainable`, `.trainable_variables`, `.save_weights`, `.summary`) and
+add the explicit `forward` / `backward` pair the MI355X train_step drives (no tapes, no autograd):
+every FLOP runs in libscrabble_hip.so.
+
+Deliberate, documented behaviours carried over from the reference:
+  * kernel_reg (spectral_norm) is accepted and, like Keras' lazily-evaluated regularizer losses that
+    nobody reads, NOT applied to the weights in the forward pass (fact 2);
+  * NonLocalBlock kernels are re-drawn (orthogonal) on every call and untrained in nl_mode='reference'
+    (fact 3); nl_mode='persistent' keeps them as trainable weights (the evident intent);
+  * the recognizer's BatchNorm runs in inference mode whenever the model is frozen (fact 4).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import nn, ops
+from .nn import LOCAL, ParamStore, Reducer
+
+
+def get_in_out_channels_gen(resolution=32):
+    ch = 64
+    if resolution == 32:
+        mult = [8, 4, 2, 1]
+    else:
+        raise ValueError("Unsupported resolution: {}".format(resolution))
+    return [ch * c for c in mult[:-1]], [ch * c for c in mult[1:]]
+
+
+def get_in_out_channels_disc(colors=1, resolution=32):
+    ch = 64
+    if colors not in [1, 3]:
+        raise ValueError("Unsupported color channels: {}".format(colors))
+    if resolution == 32:
+        mult = [1, 8, 16, 16]
+    else:
+        raise ValueError("Unsupported resolution: {}".format(resolution))
+    out_channels = [ch * c for c in mult]
+    return [colors] + out_channels[:-1], out_channels
+
+
+_DEFAULTS = {"device": None, "seed": 0, "nl_mode": "reference", "reducer": LOCAL}
+
+
+def configure(device=None, seed=None, nl_mode=None, reducer=None):
+    """Process-wide construction defaults (device, init seed, NonLocalBlock mode, DP reducer)."""
+    if device is not None:
+        _DEFAULTS["device"] = torch.device(device)
+    if seed is not None:
+        _DEFAULTS["seed"] = seed
+    if nl_mode is not None:
+        assert nl_mode in ("reference", "persistent")
+        _DEFAULTS["nl_mode"] = nl_mode
+    if reducer is not None:
+        _DEFAULTS["reducer"] = reducer
+
+
+def _device():
+    if _DEFAULTS["device"] is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("scrabble_gan_amd needs an MI355X (no HIP device visible); there is no CPU path")
+        _DEFAULTS["device"] = torch.device("cuda", torch.cuda.current_device())
+    return _DEFAULTS["device"]
+
+
+_model_counter = [0]
+
+
+def _gen_for(name: str) -> torch.Generator:
+    _model_counter[0] += 1
+    return torch.Generator().manual_seed(_DEFAULTS["seed"] * 1000 + _model_counter[0])
+
+
+class _Model:
+    """The slice of tf.keras.Model that main.py / data_utils.py use."""
+
+    def __init__(self, name: str, specs, gen: torch.Generator):
+        self.name = name
+        self.device = _device()
+        self.store = ParamStore(specs, self.device, gen)
+        self.trainable = True
+        self.reducer: Reducer = _DEFAULTS["reducer"]
+
+    @property
+    def trainable_variables(self) -> List[torch.Tensor]:
+        if not self.trainable:
+            return []
+        return [self.store.p[n] for n in self.store.trainable_names()]
+
+    @property
+    def variables(self) -> Dict[str, torch.Tensor]:
+        return dict(self.store.p)
+
+    def count_params(self) -> int:
+        return self.store.num_params()
+
+    def summary(self):
+        print('Model: "%s"' % self.name)
+        for n in self.store.names:
+            print("  %-28s %-22s %s" % (n, tuple(self.store.shapes[n]), "" if self.store.trainable[n] else "(non-trainable)"))
+        print("Trainable params: {:,}".format(self.count_params()))
+
+    def save_weights(self, prefix: str):
+        """generator.save_weights(prefix) (data_utils.py:346-348).  Written as <prefix>.safetensors."""
+        from safetensors.torch import save_file
+        d = os.path.dirname(prefix)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        save_file({k: v.contiguous() for k, v in self.store.export().items()}, prefix + ".safetensors")
+
+    def load_weights(self, prefix: str):
+        from safetensors.torch import load_file
+        self.store.load(load_file(prefix + ".safetensors"))
+
+
+# --------------------------------------------------------------------------------------------
+# the 4-block "down" trunk shared by D, the style promoter and G's style encoder
+# --------------------------------------------------------------------------------------------
+class _DownTrunk:
+    def __init__(self, block_fmt: str, attn_blocks: str, colors: int, resolution: int, nl_mode: str):
+        self.cin, self.cout = get_in_out_channels_disc(colors, resolution)
+        self.names = [block_fmt.format(i + 1) for i in range(len(self.cin))]
+        self.attn = [n for n in self.names if n in attn_blocks]          # substring test (net_architecture.py:278,336)
+        self.nl_mode = nl_mode
+
+    def specs(self):
+        s = []
+        for n, ci, co in zip(self.names, self.cin, self.cout):
+            s += nn.block_down_specs(n, ci, co)
+            if n in self.attn:
+                s.append(("NL_" + n + ".sigma", (), nn.zeros, True))
+                if self.nl_mode == "persistent":
+                    s += [("NL_" + n + ".theta", (co, co // 8), nn.orthogonal, True), ("NL_" + n + ".phi", (co, co // 8), nn.orthogonal, True),
+                          ("NL_" + n + ".g", (co, co // 2), nn.orthogonal, True), ("NL_" + n + ".o", (co // 2, co), nn.orthogonal, True)]
+        return s
+
+    def _nlw(self, S: ParamStore, n: str, C: int, nl, nl_gen):
+        if self.nl_mode == "persistent":
+            return {k: S.p["NL_" + n + "." + k] for k in ("theta", "phi", "g", "o")}
+        if nl is not None:
+            return nl
+        return nn.nonlocal_weights(C, nl_gen, S.device)       # fact 3: fresh orthogonal kernels per call
+
+    def fwd(self, x, S: ParamStore, nl=None, nl_gen=None):
+        ctxs = []
+        net = x
+        for i, n in enumerate(self.names):
+            net, c = nn.block_down_fwd(net, S, n, is_last=(i == len(self.names) - 1))
+            nlc = None
+            if n in self.attn:
+                net, nlc = nn.nonlocal_fwd(net, self._nlw(S, n, self.cout[i], nl, nl_gen), S.p["NL_" + n + ".sigma"])
+            ctxs.append((c, nlc))
+        h = ops.gap_fwd(net, relu=True)                         # tf.nn.relu + GlobalAveragePooling2D
+        return h, (ctxs, net)
+
+    def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool):
+        ctxs, net = ctx
+        d = ops.gap_bwd(dh, net, relu=True)
+        for i in reversed(range(len(self.names))):
+            n = self.names[i]
+            c, nlc = ctxs[i]
+            if nlc is not None:
+                dsig = S.g["NL_" + n + ".sigma"] if want_dw else torch.zeros(1, device=S.device)
+                dnlw = None
+                if self.nl_mode == "persistent" and want_dw:
+                    dnlw = {k: S.g["NL_" + n + "." + k] for k in ("theta", "phi", "g", "o")}
+                d = nn.nonlocal_bwd(nlc, d, S.p["NL_" + n + ".sigma"], dsig, dnlw)
+            d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw)
+        return d
+
+
+class DiscriminatorModel(_Model):
+    """make_discriminator / make_style_promoter body: trunk -> Dense(1, no bias)."""
+
+    def __init__(self, name, input_dim, kernel_reg, blocks_with_attention):
+        h, w, c = input_dim
+        self.trunk = _DownTrunk("B{}", blocks_with_attention, c, h, _DEFAULTS["nl_mode"])
+        gen = _gen_for(name)
+        super().__init__(name, self.trunk.specs() + [("dense.w", (self.trunk.cout[-1], 1), nn.orthogonal, True)], gen)
+        self.kernel_reg = kernel_reg
+        self.nl_gen = torch.Generator().manual_seed(gen.initial_seed() + 7)
+
+    def forward(self, x, nl=None):
+        x = _as_nhwc1(x, self.device)
+        h, tctx = self.trunk.fwd(x, self.store, nl, self.nl_gen)
+        logits = ops.dense_fwd(h, self.store.p["dense.w"])                     # [B,1]
+        return logits, (tctx, h)
+
+    def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool):
+        tctx, h = ctx
+        dlogits = dlogits.reshape(-1, 1).contiguous()
+        if want_dw:
+            ops.dense_bwd_weight(h, dlogits, self.store.g["dense.w"])
+        dh = ops.dense_bwd_input(dlogits, self.store.p["dense.w"])
+        return self.trunk.bwd(tctx, dh, self.store, want_dx, want_dw)
+
+    def __call__(self, inputs, training=False):
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        return self.forward(x)[0]
+
+
+def _as_nhwc1(x, device):
+    """Accept numpy / torch, [B,H,W] or [B,H,W,1]; cast to fp32 on the device."""
+    if not torch.is_tensor(x):
+        import numpy as np
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if x.dim() == 3:
+        x = x.unsqueeze(-1)
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _as_labels(y, device):
+    if not torch.is_tensor(y):
+        import numpy as np
+        y = torch.from_numpy(np.ascontiguousarray(y))
+    return y.to(device=device, dtype=torch.int32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# generator
+# --------------------------------------------------------------------------------------------
+class GeneratorModel(_Model):
+    def __init__(self, latent_dim, input_dim, embed_y, kernel_reg, blocks_with_attention, vocab_size):
+        h, w, c = input_dim
+        self.in_ch, self.out_ch = get_in_out_channels_gen(h)
+        if tuple(embed_y) != (32, 8192):
+            raise ValueError("embed_y must be (32, 8192): the seed reshape hard-codes 512x4x4 (net_architecture.py:269-270)")
+        self.trunk = _DownTrunk("B_style{}", "B_style1", c, h, _DEFAULTS["nl_mode"])      # :241-246
+        self.up_names = ["B{}".format(i + 1) for i in range(len(self.in_ch))]
+        self.up_attn = [n for n in self.up_names if n in blocks_with_attention]           # :278
+        specs = self.trunk.specs() + [("zdense.w", (self.trunk.cout[-1], 128), nn.orthogonal, True),
+                                      ("filter_bank", (vocab_size, embed_y[0], embed_y[1]), nn.glorot_uniform, True)]
+        for n, ci, co in zip(self.up_names, self.in_ch, self.out_ch):
+            specs += nn.block_up_specs(n, ci, co)
+            if n in self.up_attn:
+                specs.append(("NL_" + n + ".sigma", (), nn.zeros, True))
+                if _DEFAULTS["nl_mode"] == "persistent":
+                    specs += [("NL_" + n + ".theta", (co, co // 8), nn.orthogonal, True), ("NL_" + n + ".phi", (co, co // 8), nn.orthogonal, True),
+                              ("NL_" + n + ".g", (co, co // 2), nn.orthogonal, True), ("NL_" + n + ".o", (co // 2, co), nn.orthogonal, True)]
+        cl = self.out_ch[-1]
+        specs += [("bn.gamma", (cl,), nn.ones, True), ("bn.beta", (cl,), nn.zeros, True),
+                  ("bn.mm", (cl,), nn.zeros, False), ("bn.mv", (cl,), nn.ones, False),
+                  ("final.w", (3, 3, cl, c), nn.orthogonal, True), ("final.b", (c,), nn.zeros, True)]
+        gen = _gen_for("generator")
+        super().__init__("generator", specs, gen)
+        self.nl_mode = _DEFAULTS["nl_mode"]
+        self.nl_gen = torch.Generator().manual_seed(gen.initial_seed() + 7)
+        self.kernel_reg = kernel_reg
+        self.latent_dim = latent_dim          # unused, as in the reference (Appendix C-9)
+
+    def _up_nlw(self, n, C, nl):
+        if self.nl_mode == "persistent":
+            return {k: self.store.p["NL_" + n + "." + k] for k in ("theta", "phi", "g", "o")}
+        return nl if nl is not None else nn.nonlocal_weights(C, self.nl_gen, self.device)
+
+    def forward(self, style, y, nl_style=None, nl_up=None, training=True):
+        S, p = self.store, self.store.p
+        style = _as_nhwc1(style, self.device)
+        y = _as_labels(y, self.device)
+        h, tctx = self.trunk.fwd(style, S, nl_style, self.nl_gen)                 # :241-250
+        z = ops.dense_fwd(h, p["zdense.w"])                                        # :251-257  [B,128]
+        net = ops.filterbank_fwd(z, y, p["filter_bank"])                           # :229-231,259-271
+        up_ctx = []
+        for i, n in enumerate(self.up_names):
+            if training:
+                net, c = nn.block_up_fwd(net, z, i + 1, S, n, i == len(self.up_names) - 1, self.reducer)
+            else:
+                net, c = _block_up_infer(net, z, i + 1, S, n, i == len(self.up_names) - 1), None
+            nlc = None
+            if n in self.up_attn:
+                net, nlc = nn.nonlocal_fwd(net, self._up_nlw(n, self.out_ch[i], nl_up), p["NL_" + n + ".sigma"])
+            up_ctx.append((c, nlc))
+        if training:
+            yb, bctx = nn.bn_train_fwd(net, p["bn.gamma"], p["bn.beta"], False, True, self.reducer)   # :281-282
+            ops.bn_update_moving(p["bn.mm"], p["bn.mv"], bctx[2], bctx[3], bctx[5])
+        else:
+            yb, bctx = ops.bn_apply(net, p["bn.mm"], p["bn.mv"], p["bn.gamma"], p["bn.beta"], False, True), None
+        img = ops.conv2d_fwd(yb, p["final.w"], p["final.b"], tanh_out=True)        # :283-289
+        return img, (tctx, h, z, y, up_ctx, bctx, yb, img)
+
+    def backward(self, ctx, dimg):
+        S, p, g = self.store, self.store.p, self.store.g
+        tctx, h, z, y, up_ctx, bctx, yb, img = ctx
+        d_pre = ops.tanh_bwd(img, dimg)
+        ops.conv2d_bwd_weight(yb, d_pre, g["final.w"])
+        ops.bias_grad(d_pre, g["final.b"])
+        dyb = ops.conv2d_bwd_data(d_pre, p["final.w"], (yb.shape[1], yb.shape[2]))
+        d, _, _, _ = nn.bn_train_bwd(bctx, dyb, False, True, self.reducer, dgamma_c=g["bn.gamma"], dbeta_c=g["bn.beta"])
+        dz = torch.zeros_like(z)
+        for i in reversed(range(len(self.up_names))):
+            n = self.up_names[i]
+            c, nlc = up_ctx[i]
+            if nlc is not None:
+                dnlw = {k: g["NL_" + n + "." + k] for k in ("theta", "phi", "g", "o")} if self.nl_mode == "persistent" else None
+                d = nn.nonlocal_bwd(nlc, d, p["NL_" + n + ".sigma"], g["NL_" + n + ".sigma"], dnlw)
+            d = nn.block_up_bwd(c, d, z, dz, i + 1, S, n, self.reducer)
+        ops.filterbank_bwd(z, y, p["filter_bank"], d, g["filter_bank"], dz)
+        ops.dense_bwd_weight(h, dz, g["zdense.w"])
+        dh = ops.dense_bwd_input(dz, p["zdense.w"])
+        self.trunk.bwd(tctx, dh, S, want_dx=False, want_dw=True)
+
+    def __call__(self, inputs, training=False):
+        style, y = inputs[0], inputs[1]
+        return self.forward(style, y, training=training)[0]
+
+
+def _block_up_infer(x, z, zi, S: ParamStore, pre: str, is_last: bool):
+    """ResNetBlockUp with BatchNorm in inference mode (moving statistics): generator(..., training=False)
+    of data_utils.py:507."""
+    p = S.p
+    stride = (2, 1) if is_last else (2, 2)
+    B = x.shape[0]
+
+    def cbn(t, name):
+        C = t.shape[-1]
+        gamma = ops.gemm(z, p[name + ".gamma.w"], B, C, 32, 128, C, A_off=32 * zi)
+        beta = ops.gemm(z, p[name + ".beta.w"], B, C, 32, 128, C, A_off=32 * zi)
+        return ops.bn_apply(t, p[name + ".mm"], p[name + ".mv"], gamma, beta, True, True)
+    t = ops.conv2d_transpose_fwd(cbn(x, pre + ".cbn1"), p[pre + ".convT.w"], p[pre + ".convT.b"], stride=stride)
+    out = ops.conv2d_fwd(cbn(t, pre + ".cbn2"), p[pre + ".conv.w"], p[pre + ".conv.b"])
+    ops.conv2d_transpose_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"], stride=stride, out=out, accum=True)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# recognizer (fully convolutional CRNN + CTC): make_recognizer, net_architecture.py:9-79
+# --------------------------------------------------------------------------------------------
+_REC = [(3, 64, (2, 2)), (3, 128, (2, 2)), (3, 256, None), (3, 256, (2, 1)), (3, 512, None), (3, 512, (2, 1)), (2, 512, None)]
+
+
+class RecognizerModel(_Model):
+    def __init__(self, input_dim, sequence_length, output_classes):
+        h, w, c = input_dim
+        specs, cin = [], c
+        for i, (k, co, _) in enumerate(_REC):
+            specs += [("conv%d.w" % (i + 1), (k, k, cin, co), nn.glorot_uniform, True), ("conv%d.b" % (i + 1), (co,), nn.zeros, True)]
+            cin = co
+        for pre in ("bn5", "bn6"):
+            specs += [(pre + ".gamma", (512,), nn.ones, True), (pre + ".beta", (512,), nn.zeros, True),
+                      (pre + ".mm", (512,), nn.zeros, False), (pre + ".mv", (512,), nn.ones, False)]
+        specs += [("dense.w", (512, output_classes), nn.glorot_uniform, True), ("dense.b", (output_classes,), nn.zeros, True)]
+        super().__init__("recognizer", specs, _gen_for("recognizer"))
+        self.classes = output_classes
+
+    def _bn_fwd(self, x, pre, bn_training):
+        p = self.store.p
+        if bn_training:
+            y, ctx = nn.bn_train_fwd(x, p[pre + ".gamma"], p[pre + ".beta"], False, False, self.reducer)
+            ops.bn_update_moving(p[pre + ".mm"], p[pre + ".mv"], ctx[2], ctx[3], ctx[5])
+            return y, ("train", ctx)
+        y = ops.bn_apply(x, p[pre + ".mm"], p[pre + ".mv"], p[pre + ".gamma"], p[pre + ".beta"], False, False)
+        return y, ("infer", x)
+
+    def _bn_bwd(self, ctx, dy, pre, want_dw):
+        p, g = self.store.p, self.store.g
+        dg, db = (g[pre + ".gamma"], g[pre + ".beta"]) if want_dw else (None, None)
+        if ctx[0] == "train":
+            return nn.bn_train_bwd(ctx[1], dy, False, False, self.reducer, dgamma_c=dg, dbeta_c=db)[0]
+        x = ctx[1]
+        if want_dw:
+            ops.bn_bwd_reduce(dy, None, x, p[pre + ".mm"], p[pre + ".mv"], p[pre + ".gamma"], False, False, dgamma_c=dg, dbeta_c=db)
+        return ops.bn_bwd_apply(dy, None, x, p[pre + ".mm"], p[pre + ".mv"], p[pre + ".gamma"], False, None, 1, False, False)
+
+    def forward(self, x, labels, input_length, label_length, training=True, need_grad=True):
+        """-> per-sample CTC cost [B] (the model's OUTPUT is the loss, net_architecture.py:71-74), ctx."""
+        p = self.store.p
+        x = _as_nhwc1(x, self.device)
+        labels = _as_labels(labels, self.device)
+        bn_training = bool(training and self.trainable)        # TF2: training AND layer.trainable (fact 4)
+        acts, net = [], x
+        for i, (k, co, pool) in enumerate(_REC):
+            a = ops.conv2d_fwd(net, p["conv%d.w" % (i + 1)], p["conv%d.b" % (i + 1)], same=(k == 3), relu_out=True)
+            rec = {"in": net, "a": a}
+            net = a
+            if i in (4, 5):
+                net, rec["bn"] = self._bn_fwd(net, "bn%d" % (i + 1), bn_training)
+            if pool is not None:
+                net, rec["idx"] = ops.maxpool_fwd(net, *pool)
+            acts.append(rec)
+        B, one, T, C = net.shape
+        assert one == 1, net.shape
+        feat = net.view(B * T, C)
+        logits = ops.dense_fwd(feat, p["dense.w"], p["dense.b"]).view(B, T, self.classes)     # Dense (softmax fused below)
+        loss, dlogits = ops.softmax_ctc(logits, labels, int(input_length), int(label_length), need_grad)
+        return loss, (acts, feat, dlogits, (B, T))
+
+    def backward(self, ctx, upstream, want_dx: bool, want_dw: bool):
+        """upstream [B] = d(target)/d(cost_b).  Returns d(target)/d(images) if want_dx."""
+        p, g = self.store.p, self.store.g
+        acts, feat, dlogits_unit, (B, T) = ctx
+        dl = ops.rowscale(dlogits_unit, upstream.reshape(-1).contiguous()).view(B * T, self.classes)
+        if want_dw:
+            ops.dense_bwd_weight(feat, dl, g["dense.w"])
+            ops.bias_grad(dl, g["dense.b"])
+        d = ops.dense_bwd_input(dl, p["dense.w"]).view(B, 1, T, feat.shape[1])
+        for i in reversed(range(len(_REC))):
+            k, co, pool = _REC[i]
+            rec = acts[i]
+            if pool is not None:
+                d = ops.maxpool_bwd(d, rec["idx"], *pool)
+            if "bn" in rec:
+                d = self._bn_bwd(rec["bn"], d, "bn%d" % (i + 1), want_dw)
+            d = ops.relu_mask(d, rec["a"])                       # activation='relu' backward (mask by the output)
+            if want_dw:
+                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % (i + 1)], same=(k == 3))
+                ops.bias_grad(d, g["conv%d.b" % (i + 1)])
+            if i == 0 and not want_dx:
+                return None
+            xin = rec["in"]
+            d = ops.conv2d_bwd_data(d, p["conv%d.w" % (i + 1)], (xin.shape[1], xin.shape[2]), same=(k == 3))
+        return d
+
+    def __call__(self, inputs, training=False):
+        x, labels, il, ll = inputs
+        return self.forward(x, labels, int(_scalar(il)), int(_scalar(ll)), training, need_grad=False)[0].view(-1, 1)
+
+
+def _scalar(v):
+    if torch.is_tensor(v):
+        return v.reshape(-1)[0].item()
+    try:
+        import numpy as np
+        return np.asarray(v).reshape(-1)[0]
+    except Exception:
+        return v
+
+
+class CompositeGAN:
+    """make_gan (net_architecture.py:531-561): G -> {D, R, S}; freezing D/R/S leaves G's variables
+    as the composite's trainable_variables."""
+
+    def __init__(self, g_model, d_model, r_model, w_model):
+        self.generator, self.discriminator, self.recognizer, self.style_promoter = g_model, d_model, r_model, w_model
+
+    @property
+    def trainable_variables(self):
+        out = []
+        for m in (self.generator, self.discriminator, self.recognizer, self.style_promoter):
+            out += m.trainable_variables
+        return out
+
+    def __call__(self, inputs, training=False):
+        style, y, il, ll = inputs
+        img = self.generator.forward(style, y, training=training)[0]
+        d = self.discriminator.forward(img)[0]
+        r = self.recognizer.forward(img, y, int(_scalar(il)), int(_scalar(ll)), training, need_grad=False)[0].view(-1, 1)
+        s = self.style_promoter.forward(img)[0]
+        return [img, d, r, s]
+
+
+# --------------------------------------------------------------------------------------------
+# factories (reference names, positional order and defaults)
+# --------------------------------------------------------------------------------------------
+def make_generator(latent_dim, input_dim, embed_y, kernel_reg, blocks_with_attention, vocab_size, vis_model=True):
+    m = GeneratorModel(latent_dim, input_dim, embed_y, kernel_reg, blocks_with_attention, vocab_size)
+    if vis_model:
+        m.summary()
+    return m
+
+
+def make_discriminator(input_dim, kernel_reg, blocks_with_attention, vis_model=True):
+    m = DiscriminatorModel("discriminator", input_dim, kernel_reg, blocks_with_attention)
+    if vis_model:
+        m.summary()
+    return m
+
+
+def make_style_promoter(input_dim, kernel_reg, blocks_with_attention, vis_model=True):
+    m = DiscriminatorModel("style_promoter", input_dim, kernel_reg, blocks_with_attention)
+    if vis_model:
+        m.summary()
+    return m
+
+
+def make_recognizer(input_dim, sequence_length, output_classes, vis_model=True):
+    m = RecognizerModel(input_dim, sequence_length, output_classes)
+    if vis_model:
+        m.summary()
+    return m
+
+
+def make_my_recognizer(input_dim, sequence_length, output_classes, vis_model=True):
+    """CRNN with 5 BiLSTM layers (net_architecture.py:82-179), gin default off (`my_rec=0`).
+    Not built yet: the LSTM recurrences need their own kernels ('not yet built')."""
+    raise NotImplementedError("make_my_recognizer (BiLSTM recognizer) is not built in this round; use make_recognizer "
+                              "(scrabble_gan.gin: shared_specs.my_rec=0)")
+
+
+def make_gan(g_model, d_model, r_model, w_model, vis_model=True):
+    d_model.trainable = False          # :543-545
+    r_model.trainable = False
+    w_model.trainable = False
+    return CompositeGAN(g_model, d_model, r_model, w_model)

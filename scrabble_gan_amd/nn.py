@@ -1,0 +1,295 @@
+"""Host-side building blocks: flat parameter stores and the explicit forward/backward of every
+block of the ScrabbleGAN nets, expressed over the C-ABI kernels in `ops`.
+
+There is no autograd: each `*_fwd` returns (output, ctx) and the matching `*_bwd` consumes ctx,
+accumulates weight gradients into the store's flat gradient buffer (the kernels' += contract) and
+returns the input gradient.  That keeps the four "tapes" of the reference train_step
+(/root/reference/src/bigacgan/data_utils.py:398-468) as four explicit backward sweeps over saved
+contexts, lets D/S passes on different batches share one gradient buffer, and makes the flat
+buffers directly all-reducible (RCCL) and updatable (one fused Adam launch per network).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+
+# --------------------------------------------------------------------------------------------
+# initialisers (Keras semantics; host-side, run once)
+# --------------------------------------------------------------------------------------------
+def orthogonal(shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
+    """tf.initializers.orthogonal(gain=1): QR of a N(0,1) matrix flattened to [prod(shape[:-1]), shape[-1]]."""
+    rows, cols = int(math.prod(shape[:-1])), int(shape[-1])
+    a = torch.randn((cols, rows) if rows < cols else (rows, cols), generator=gen, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r))
+    if rows < cols:
+        q = q.t()
+    return q.reshape(tuple(shape)).float().contiguous()
+
+
+def glorot_uniform(shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(math.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return ((torch.rand(tuple(shape), generator=gen, dtype=torch.float64) * 2 - 1) * lim).float()
+
+
+def zeros(shape, gen=None):
+    return torch.zeros(tuple(shape))
+
+
+def ones(shape, gen=None):
+    return torch.ones(tuple(shape))
+
+
+# --------------------------------------------------------------------------------------------
+# flat parameter store
+# --------------------------------------------------------------------------------------------
+class ParamStore:
+    """All trainable variables of one network in ONE flat fp32 buffer (16-byte aligned slices),
+    with a same-shaped flat gradient buffer; non-trainable state (BN moving statistics) in a
+    second flat buffer.  `p[name]` / `g[name]` are views."""
+
+    def __init__(self, specs: List[Tuple[str, Tuple[int, ...], Callable, bool]], device, gen: torch.Generator):
+        self.device = device
+        self.names: List[str] = []
+        self.shapes: Dict[str, Tuple[int, ...]] = {}
+        self.trainable: Dict[str, bool] = {}
+        offs = {True: 0, False: 0}
+        self._off: Dict[str, int] = {}
+        host = {}
+        for name, shape, init, trainable in specs:
+            assert name not in self.shapes, name
+            self.names.append(name)
+            self.shapes[name] = tuple(shape)
+            self.trainable[name] = trainable
+            self._off[name] = offs[trainable]
+            n = int(math.prod(shape)) if len(shape) else 1
+            offs[trainable] += (n + 3) // 4 * 4
+            host[name] = init(shape, gen).reshape(-1).float()
+        self.flat = torch.zeros(max(offs[True], 4), device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.state = torch.zeros(max(offs[False], 4), device=device)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for name in self.names:
+            n = host[name].numel()
+            o = self._off[name]
+            buf = self.flat if self.trainable[name] else self.state
+            view = buf[o:o + n].view(self.shapes[name])
+            view.copy_(host[name].view(self.shapes[name]))
+            self.p[name] = view
+            if self.trainable[name]:
+                self.g[name] = self.grad[o:o + n].view(self.shapes[name])
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def trainable_names(self) -> List[str]:
+        return [n for n in self.names if self.trainable[n]]
+
+    def load(self, weights: Dict[str, torch.Tensor]):
+        for k, v in weights.items():
+            self.p[k].copy_(v.reshape(self.shapes[k]).to(self.device, torch.float32))
+
+    def export(self) -> Dict[str, torch.Tensor]:
+        return {k: self.p[k].detach().cpu().clone() for k in self.names}
+
+    def num_params(self) -> int:
+        return sum(int(math.prod(self.shapes[n])) if self.shapes[n] else 1 for n in self.trainable_names())
+
+
+class Reducer:
+    """Cross-rank sum hook (data parallel).  The default is the identity (one process)."""
+
+    world_size = 1
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+
+LOCAL = Reducer()
+
+
+# --------------------------------------------------------------------------------------------
+# ResNetBlockDown (/root/reference/src/bigacgan/resnet_ops.py:84-120)
+# --------------------------------------------------------------------------------------------
+def block_down_specs(pre: str, cin: int, cout: int):
+    return [(pre + ".conv1.w", (3, 3, cin, cout), orthogonal, True), (pre + ".conv1.b", (cout,), zeros, True),
+            (pre + ".conv2.w", (3, 3, cout, cout), orthogonal, True), (pre + ".conv2.b", (cout,), zeros, True),
+            (pre + ".short.w", (1, 1, cin, cout), orthogonal, True), (pre + ".short.b", (cout,), zeros, True)]
+
+
+def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
+    p = S.p
+    c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True)          # :97-99
+    if is_last:
+        out = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])                     # :109-111
+        ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True, out=out, accum=True)   # :102-104,114
+    else:
+        c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
+        s = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])
+        out = ops.avgpool2_add_fwd(c2, s)                                                     # :105-106,112-114
+    return out, (x, c1)
+
+
+def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: bool, want_dw: bool):
+    x, c1 = ctx
+    p, g = S.p, S.g
+    H, W = x.shape[1], x.shape[2]
+    d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of both conv2's output and the 1x1 output
+    if want_dw:
+        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True)
+        ops.bias_grad(d_c2, g[pre + ".conv2.b"])
+        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"])
+        ops.bias_grad(d_c2, g[pre + ".short.b"])
+    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1)
+    if want_dw:
+        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True)
+        ops.bias_grad(d_c1, g[pre + ".conv1.b"])
+    if not want_dx:
+        return None
+    dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
+    ops.conv2d_bwd_data(d_c1, p[pre + ".conv1.w"], (H, W), mask=x, out=dx, accum=True)
+    return dx
+
+
+# --------------------------------------------------------------------------------------------
+# NonLocalBlock (/root/reference/src/bigacgan/arch_ops.py:5-72) as a pure function of its kernels
+# --------------------------------------------------------------------------------------------
+def nonlocal_weights(C: int, gen: torch.Generator, device) -> Dict[str, torch.Tensor]:
+    """The four orthogonal 1x1 kernels NonLocalBlock.call builds (arch_ops.py:38-65)."""
+    return {"theta": orthogonal((1, 1, C, C // 8), gen).to(device), "phi": orthogonal((1, 1, C, C // 8), gen).to(device),
+            "g": orthogonal((1, 1, C, C // 2), gen).to(device), "o": orthogonal((1, 1, C // 2, C), gen).to(device)}
+
+
+def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor):
+    B, H, W, C = x.shape
+    w_t, w_p, w_g, w_o = (nlw[k].view(1, 1, *nlw[k].shape[-2:]) for k in ("theta", "phi", "g", "o"))
+    theta = ops.conv2d_fwd(x, w_t)                                         # :38-41
+    phi, i_phi = ops.maxpool_fwd(ops.conv2d_fwd(x, w_p), 2, 2)             # :44-48
+    gg, i_g = ops.maxpool_fwd(ops.conv2d_fwd(x, w_g), 2, 2)                # :55-59
+    Nq, Nk = H * W, (H // 2) * (W // 2)
+    o, lse = ops.attention_fwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2))   # :51-52,61
+    oc = ops.conv2d_fwd(o.view(B, H, W, C // 2), w_o)                      # :62-65
+    out = ops.scale_add(oc, x, sigma.view(1))                              # :67
+    return out, (x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o))
+
+
+def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Optional[Dict[str, torch.Tensor]] = None):
+    x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o) = ctx
+    B, H, W, C = x.shape
+    Nq, Nk = H * W, (H // 2) * (W // 2)
+    ops.dot_accum(dout, oc, dsigma.view(1))
+    d_oc = ops.scale(dout, sigma.view(1))
+    d_o = ops.conv2d_bwd_data(d_oc, w_o, (H, W))
+    dth, dph, dg = ops.attention_bwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2),
+                                     o.view(B, Nq, C // 2), lse, d_o.view(B, Nq, C // 2))
+    dth = dth.view(B, H, W, C // 8)
+    dph_f = ops.maxpool_bwd(dph.view(B, H // 2, W // 2, C // 8), i_phi, 2, 2)
+    dg_f = ops.maxpool_bwd(dg.view(B, H // 2, W // 2, C // 2), i_g, 2, 2)
+    if dnlw is not None:     # 'persistent' mode: the 1x1 kernels are trainable
+        ops.conv2d_bwd_weight(o.view(B, H, W, C // 2), d_oc, dnlw["o"].view(1, 1, C // 2, C))
+        ops.conv2d_bwd_weight(x, dth, dnlw["theta"].view(1, 1, C, C // 8))
+        ops.conv2d_bwd_weight(x, dph_f, dnlw["phi"].view(1, 1, C, C // 8))
+        ops.conv2d_bwd_weight(x, dg_f, dnlw["g"].view(1, 1, C, C // 2))
+    dx = ops.conv2d_bwd_data(dth, w_t, (H, W))
+    ops.conv2d_bwd_data(dph_f, w_p, (H, W), out=dx, accum=True)
+    ops.conv2d_bwd_data(dg_f, w_g, (H, W), out=dx, accum=True)
+    return ops.add(dx, dout, out=dx)
+
+
+# --------------------------------------------------------------------------------------------
+# batch norm with batch statistics (+ per-sample affine = ConditionalBatchNorm, resnet_ops.py:5-33)
+# --------------------------------------------------------------------------------------------
+def bn_train_fwd(x, gamma, beta, per_sample: bool, relu: bool, reducer: Reducer = LOCAL):
+    B, H, W, C = x.shape
+    sums = reducer.all_reduce_sum(ops.bn_stats_sums(x))          # SyncBN: (sum x, sum x^2) over all ranks
+    count = B * H * W * reducer.world_size
+    mean, var = ops.bn_stats_finalize(sums, count, x)
+    y = ops.bn_apply(x, mean, var, gamma, beta, per_sample, relu)
+    return y, (x, y, mean, var, gamma, count)
+
+
+def bn_train_bwd(ctx, dy, per_sample: bool, relu: bool, reducer: Reducer = LOCAL, dgamma_c=None, dbeta_c=None):
+    """-> dx, dgamma [B,C], dbeta [B,C] (per-sample sums), chan (fp64 [4C]); dgamma_c/dbeta_c [C] += per-channel grads."""
+    x, y, mean, var, gamma, count = ctx
+    dgamma, dbeta, chan = ops.bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample, relu, dgamma_c=dgamma_c, dbeta_c=dbeta_c)
+    if reducer.world_size > 1:
+        C = x.shape[-1]
+        red = reducer.all_reduce_sum(chan[:2 * C].clone())
+        chan = torch.cat([red, chan[2 * C:]])
+    dx = ops.bn_bwd_apply(dy, y, x, mean, var, gamma, per_sample, chan, count, relu, True)
+    return dx, dgamma, dbeta, chan
+
+
+# --------------------------------------------------------------------------------------------
+# ResNetBlockUp (/root/reference/src/bigacgan/resnet_ops.py:36-81)
+# --------------------------------------------------------------------------------------------
+def block_up_specs(pre: str, cin: int, cout: int):
+    return [(pre + ".cbn1.gamma.w", (32, cin), orthogonal, True), (pre + ".cbn1.beta.w", (32, cin), orthogonal, True),
+            (pre + ".convT.w", (3, 3, cout, cin), orthogonal, True), (pre + ".convT.b", (cout,), zeros, True),
+            (pre + ".cbn2.gamma.w", (32, cout), orthogonal, True), (pre + ".cbn2.beta.w", (32, cout), orthogonal, True),
+            (pre + ".conv.w", (3, 3, cout, cout), orthogonal, True), (pre + ".conv.b", (cout,), zeros, True),
+            (pre + ".short.w", (1, 1, cout, cin), orthogonal, True), (pre + ".short.b", (cout,), zeros, True),
+            (pre + ".cbn1.mm", (cin,), zeros, False), (pre + ".cbn1.mv", (cin,), ones, False),
+            (pre + ".cbn2.mm", (cout,), zeros, False), (pre + ".cbn2.mv", (cout,), ones, False)]
+
+
+def _cbn_fwd(x, z, zi: int, S: ParamStore, pre: str, reducer: Reducer, update_moving: bool):
+    """z [B,128]; this block's conditioning chunk is z[:, 32*zi : 32*zi+32] (net_architecture.py:260-262)."""
+    B, C = x.shape[0], x.shape[-1]
+    gamma = ops.gemm(z, S.p[pre + ".gamma.w"], B, C, 32, 128, C, A_off=32 * zi)       # resnet_ops.py:18-21
+    beta = ops.gemm(z, S.p[pre + ".beta.w"], B, C, 32, 128, C, A_off=32 * zi)         # :24-27
+    y, ctx = bn_train_fwd(x, gamma, beta, True, True, reducer)
+    if update_moving:
+        ops.bn_update_moving(S.p[pre + ".mm"], S.p[pre + ".mv"], ctx[2], ctx[3], ctx[5])
+    return y, ctx
+
+
+def _cbn_bwd(ctx, dy, z, dz, zi: int, S: ParamStore, pre: str, reducer: Reducer):
+    dx, dgamma, dbeta, _ = bn_train_bwd(ctx, dy, True, True, reducer)
+    B, C = dgamma.shape
+    # Dense(gamma), Dense(beta) backward: weight grads [32,C] += z_i^T dgamma ; dz_i += dgamma Wg^T + dbeta Wb^T
+    ops.gemm(z, dgamma, 32, C, B, 128, C, transA=True, out=S.g[pre + ".gamma.w"], beta=1.0, A_off=32 * zi)
+    ops.gemm(z, dbeta, 32, C, B, 128, C, transA=True, out=S.g[pre + ".beta.w"], beta=1.0, A_off=32 * zi)
+    ops.gemm(dgamma, S.p[pre + ".gamma.w"], B, 32, C, C, C, transB=True, out=dz, ldc=128, beta=1.0, out_off=32 * zi)
+    ops.gemm(dbeta, S.p[pre + ".beta.w"], B, 32, C, C, C, transB=True, out=dz, ldc=128, beta=1.0, out_off=32 * zi)
+    return dx
+
+
+def block_up_fwd(x, z, zi: int, S: ParamStore, pre: str, is_last: bool, reducer: Reducer = LOCAL, update_moving=True):
+    p = S.p
+    stride = (2, 1) if is_last else (2, 2)                                                    # :54
+    y1, c1 = _cbn_fwd(x, z, zi, S, pre + ".cbn1", reducer, update_moving)                     # :50-51
+    t = ops.conv2d_transpose_fwd(y1, p[pre + ".convT.w"], p[pre + ".convT.b"], stride=stride)   # :57-59
+    y2, c2 = _cbn_fwd(t, z, zi, S, pre + ".cbn2", reducer, update_moving)                     # :62-63
+    out = ops.conv2d_fwd(y2, p[pre + ".conv.w"], p[pre + ".conv.b"])                          # :65-66
+    ops.conv2d_transpose_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"], stride=stride, out=out, accum=True)   # :69-73
+    return out, (x, c1, c2, stride)
+
+
+def block_up_bwd(ctx, dout, z, dz, zi: int, S: ParamStore, pre: str, reducer: Reducer = LOCAL):
+    x, c1, c2, stride = ctx
+    p, g = S.p, S.g
+    y1, y2 = c1[1], c2[1]
+    ops.bias_grad(dout, g[pre + ".conv.b"])
+    ops.bias_grad(dout, g[pre + ".short.b"])
+    ops.conv2d_bwd_weight(y2, dout, g[pre + ".conv.w"])
+    dy2 = ops.conv2d_bwd_data(dout, p[pre + ".conv.w"], (y2.shape[1], y2.shape[2]))
+    dt = _cbn_bwd(c2, dy2, z, dz, zi, S, pre + ".cbn2", reducer)
+    ops.conv2d_transpose_bwd_weight(y1, dt, g[pre + ".convT.w"], stride=stride)
+    ops.bias_grad(dt, g[pre + ".convT.b"])
+    dy1 = ops.conv2d_transpose_bwd_data(dt, p[pre + ".convT.w"], stride=stride)
+    dx = _cbn_bwd(c1, dy1, z, dz, zi, S, pre + ".cbn1", reducer)
+    ops.conv2d_transpose_bwd_weight(x, dout, g[pre + ".short.w"], stride=stride)
+    ops.conv2d_transpose_bwd_data(dout, p[pre + ".short.w"], stride=stride, out=dx, accum=True)
+    return dx

@@ -220,12 +220,16 @@ def rowscale(x, s):
 
 
 # ---------------------------------------------------------------- dense
-def gemm(A, B, M, N, K, lda, ldb, transA=False, transB=False, bias=None, out=None, ldc=None, alpha=1.0, beta=0.0):
+def gemm(A, B, M, N, K, lda, ldb, transA=False, transB=False, bias=None, out=None, ldc=None, alpha=1.0, beta=0.0,
+         A_off=0, out_off=0):
+    """C = alpha*op(A)*op(B) + beta*C (+bias).  A_off / out_off are element offsets into A / out, which with
+    lda / ldc address a column block of a wider row-major matrix (the z chunks of the generator)."""
     _chk(A, B, bias, out)
     if out is None:
         out = empty(M, N, like=A)
     ldc = N if ldc is None else ldc
-    call("sg_gemm", _p(A), _p(B), _p(out), _p(bias), M, N, K, lda, ldb, ldc, int(transA), int(transB), float(alpha), float(beta), _stream())
+    call("sg_gemm", A.data_ptr() + 4 * A_off, _p(B), out.data_ptr() + 4 * out_off, _p(bias), M, N, K, lda, ldb, ldc,
+         int(transA), int(transB), float(alpha), float(beta), _stream())
     return out
 
 
@@ -277,15 +281,15 @@ def bn_apply(x, mean, var, gamma, beta, per_sample: bool, relu: bool, eps=BN_EPS
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample: bool, relu: bool, eps=BN_EPS):
-    """-> dgamma [B,C], dbeta [B,C] (per-sample sums), chan fp64 [4C]."""
-    _chk(dy, y, x, mean, var, gamma)
+def bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample: bool, relu: bool, eps=BN_EPS, dgamma_c=None, dbeta_c=None):
+    """-> dgamma [B,C], dbeta [B,C] (per-sample sums), chan fp64 [4C]; dgamma_c/dbeta_c [C] += sums over b."""
+    _chk(dy, y, x, mean, var, gamma, dgamma_c, dbeta_c)
     B, H, W, C = x.shape
     dgamma = torch.zeros(B, C, device=x.device, dtype=torch.float32)
     dbeta = torch.zeros(B, C, device=x.device, dtype=torch.float32)
     chan = empty(4 * C, like=x, dtype=torch.float64)
     call("sg_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0, _p(dgamma), _p(dbeta),
-         chan.data_ptr(), B, H * W, C, eps, int(relu), _stream())
+         chan.data_ptr(), _p(dgamma_c), _p(dbeta_c), B, H * W, C, eps, int(relu), _stream())
     return dgamma, dbeta, chan
 
 

@@ -1,0 +1,147 @@
+"""Train-step throughput of the MI355X-native ScrabbleGAN hot path (BASELINE.json metric:
+train-step images/sec @ 32x160 bs128, 1/2/4/8 GPU; % of the MFMA roofline).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full train_step (8 forward passes, 4 backward sweeps, 4 Adam updates,
+/root/reference/src/bigacgan/data_utils.py:358-473) on synthetic 32x160 word crops (config c2 of
+SURVEY section 8d: global batch 128, L_r = L_f = 10, fp32), inputs resident in HBM.  The global batch
+is fixed as N grows (strong scaling, gradients SUM-all-reduced over RCCL).  Rank 0 prints ONE JSON
+line; `roofline` is the implicit-GEMM conv kernel (fwd + data-grad launches) timed with HIP events on
+its own stream, `cpu_baseline` is the CPU oracle's train_step on a bounded sample (bs 8).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE = 379.1e9            # 3 F_G + 15 F_D + 5 F_R at L_r = L_f = 10
+PEAK_FP32_MFMA_TF = 157.3           # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
+
+
+def cpu_baseline(batch=8, L=10):
+    """The oracle's train_step (torch-CPU fp32, all host cores) on a bounded sample: one step at bs 8."""
+    from oracle import scrabble_oracle as O
+    dt = torch.float32
+    g = torch.Generator().manual_seed(1)
+    G, D, S, R = O.init_generator(g, dt), O.init_discriminator(g, dt), O.init_discriminator(g, dt), O.init_recognizer(g, dt)
+    images = torch.rand(batch, 32, 16 * L, 1, generator=g, dtype=dt) * 2 - 1
+    style = torch.rand(batch, 32, 160, 1, generator=g, dtype=dt) * 2 - 1
+    labels = torch.randint(0, 52, (batch, L), generator=g)
+    fake = torch.randint(0, 52, (batch, L), generator=g)
+    nl = {k: O.init_nonlocal(64, g, dt) for k in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+    opt = {"G": {}, "D": {}, "R": {}, "S": {}}
+    t0 = time.time()
+    O.train_step(images, labels, style, fake, G, D, S, R, nl, opt)
+    dt_s = time.time() - t0
+    return {"value": batch / dt_s, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 train_step of the torch-CPU fp32 oracle at bs %d, 32x160 (stand-in for the TF2 CPU path: TensorFlow is "
+                      "not installable offline)" % batch, "seconds": dt_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="GLOBAL batch (fixed as N grows)")
+    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from scrabble_gan_amd import data_utils as DU, dist as sdist, net_architecture as NA, net_loss, ops, optimizers
+    from scrabble_gan_amd.main import build_models
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    reducer = sdist.init_from_env("nccl")
+    rank = getattr(reducer, "rank", 0)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas
+
+    in_dim = (32, 160, 1)
+    G, D, R, S, gan = build_models(in_dim, 128, (32, 8192), None, "B3", "B1", 52, None)
+    opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+
+    B, L = args.batch, args.L
+    images, labels, my_imgs = DU.synthetic_batch(B, L, in_dim, 52, seed=0)
+    words = DU.synthetic_random_words(10, 1000, 52, seed=0)
+    random.seed(0)
+    fake = np.array([random.choice(words[L - 1]) for _ in range(B)], np.int32)      # random_bucket_idx forced to L-1
+    # inputs resident in HBM before the timed region; every rank holds the global batch and takes its slice
+    images_d, my_d = torch.from_numpy(images).to(dev), torch.from_numpy(my_imgs).to(dev)
+    labels_d, fake_d = torch.from_numpy(labels).to(dev), torch.from_numpy(fake).to(dev)
+
+    def step(i):
+        return DU.train_step(0, i, args.steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
+                             net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake_d, verbose=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    ops.PROFILER = timer
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    assert all(np.isfinite(float(v)) for v in out), out
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = B * args.steps / elapsed
+        line = {
+            "metric": "train-step images/sec @ 32x160 bs128", "value": value, "unit": "images/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1"
+                                   % (B, L), "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
+            "step_algorithmic_tflops": FLOP_PER_IMAGE * (L / 10.0) * value / 1e12 if L == 10 else None,
+        }
+        if timer is not None:
+            ks = timer.summary()
+            ig = ks.get("igemm", {"tflops": 0.0, "launches": 0, "ms": 0.0})
+            line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
+                                "frac": ig["tflops"] / PEAK_FP32_MFMA_TF, "traffic": None,
+                                "kernel": "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)",
+                                "launches_per_step": ig["launches"] / args.steps, "ms_per_step": ig["ms"] / args.steps}
+            line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / args.steps, 3),
+                                   "launches_per_step": v["launches"] / args.steps} for k, v in ks.items()}
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

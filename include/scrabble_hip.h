@@ -126,6 +126,10 @@ int sg_loss_grads(const float* d_r, const float* d_f, const float* s_my, const f
                   int B, int mode, int balance, float alpha, const double* sums, float* scalars16, float* gD_r, float* gD_f,
                   float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, void* stream);
 
+/* out7 [7,B] = d_loss, d_loss_real, d_loss_fake, g_loss, s_loss, s_a, s_b per sample (the 7 tensors loss_fn returns) */
+int sg_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, int B, int mode,
+                  float* out7, void* stream);
+
 /* ---- optimizers (main.py:27-33; Keras Adam / RMSprop) and spectral_norm (arch_ops.py:98-126) */
 int sg_adam_update(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta_1, float beta_2, float eps, void* stream);
 int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream);

@@ -241,3 +241,22 @@ extern "C" int sg_loss_grads(const float* d_r, const float* d_f, const float* s_
                      balance, alpha, sums, scalars, gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r);
   return sg_launch_status();
 }
+
+// per-sample loss terms for the Python-level `hinge` / `not_saturating` callables: out[7][B] =
+// d_loss, d_loss_real, d_loss_fake, g_loss, s_loss, s_a, s_b
+__global__ __launch_bounds__(256) void k_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f,
+                                                    const float* s_r, int B, int mode, float* out) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    float d_lr, d_lf, g, s_a, s_b;
+    losses(mode, d_r[b], d_f[b], s_my[b], s_f[b], s_r[b], d_lr, d_lf, g, s_a, s_b);
+    out[b] = d_lr + d_lf; out[B + b] = d_lr; out[2 * B + b] = d_lf; out[3 * B + b] = g;
+    out[4 * B + b] = s_a + s_b; out[5 * B + b] = s_a; out[6 * B + b] = s_b;
+  }
+}
+
+extern "C" int sg_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, int B,
+                             int mode, float* out7, void* stream) {
+  if (!d_r || !d_f || !s_my || !s_f || !s_r || !out7 || B < 1) return SG_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_terms, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, B, mode, out7);
+  return sg_launch_status();
+}

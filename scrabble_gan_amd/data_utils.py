@@ -1,0 +1,252 @@
+"""The hot path and its host loop, with the reference's names and signatures
+(/root/reference/src/bigacgan/data_utils.py): train_step :358-473, apply_gradient_balancing :476-490,
+train :198-352, load_random_word_list :550-574, and the label/index bookkeeping of load_prepare_data
+:14-84.
+
+train_step keeps the 22-positional-parameter signature and the 16-scalar return.  Where the
+reference holds four GradientTapes open, this build runs the eight forward passes once, computes the
+per-sample upstream gradients of all four targets in one fused loss-head kernel, runs the backward
+sweeps against the SAME weight snapshot, and only then applies the four optimizer
+updates -- so results are those of the reference while D/S/R updates cannot leak into G's backward.
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .net_architecture import _as_labels, _as_nhwc1
+
+# ------------------------------------------------------------------------------------------------
+# label / index bookkeeping (integer: bit-exact with the reference)
+# ------------------------------------------------------------------------------------------------
+def encode_word(word: str, char_vector: str) -> List[int]:
+    """'auto' -> [0, 20, 19, 14]  (data_utils.py:49,572: char_vector.index(char))."""
+    return [char_vector.index(ch) for ch in word]
+
+
+def bucket_width(input_dim, bucket: int) -> int:
+    """image width of data bucket `bucket` (1-based): int(h/2 * bucket)  (data_utils.py:81)."""
+    return int((input_dim[0] / 2) * bucket)
+
+
+def normalize_images(image_batch: np.ndarray, input_dim, bucket: int) -> np.ndarray:
+    """uint8 [B,h,w] -> float32 [B,h,16*bucket,c] in [-1,1]: (x-127.5)/127.5  (data_utils.py:77-82)."""
+    h, _, c = input_dim
+    x = np.asarray(image_batch).astype("float32").reshape(-1, h, bucket_width(input_dim, bucket), c)
+    return (x - 127.5) / 127.5
+
+
+def ctc_input_length(sequence_length: int) -> int:
+    """-1 + sequence_length * 4  (data_utils.py:400,413)."""
+    return -1 + sequence_length * 4
+
+
+def bucket_words(words: Sequence[str], bucket_size: int, char_vector: str) -> List[List[List[int]]]:
+    """Word-list bucketing of load_random_word_list (data_utils.py:561-574): 0-based bucket = len-1,
+    words longer than bucket_size dropped, order preserved."""
+    random_words: List[List[List[int]]] = [[] for _ in range(bucket_size)]
+    for word in words:
+        word = word.strip()
+        bucket = len(word)
+        if bucket <= bucket_size:
+            random_words[bucket - 1].append(encode_word(word, char_vector))
+    return random_words
+
+
+def load_random_word_list(reading_dir, bucket_size, char_vector):
+    """random_words.txt lives three directory levels above reading_dir (data_utils.py:565-566)."""
+    path = os.path.dirname(os.path.dirname(os.path.dirname(reading_dir)))
+    with open(os.path.join(path, "random_words.txt"), "r") as f:
+        return bucket_words(list(f), bucket_size, char_vector)
+
+
+def draw_fake_labels(random_words, bucket_size: int, batch_size: int):
+    """The host draws of train_step (data_utils.py:386-387), same `random` call sequence."""
+    random_bucket_idx = random.randint(0, bucket_size - 1)
+    fake_labels = np.array([random.choice(random_words[random_bucket_idx]) for _ in range(batch_size)], np.int32)
+    return random_bucket_idx, fake_labels
+
+
+# ------------------------------------------------------------------------------------------------
+def apply_gradient_balancing(r_fake_logits, g_loss, alpha=1):
+    """data_utils.py:476-490 on device tensors: returns (g_balanced, r_loss_balanced, alpha, r_std, g_std).
+    (train_step uses the fused loss head; this mirrors the public helper.)"""
+    r = r_fake_logits.reshape(-1).contiguous()
+    g = g_loss.reshape(-1).contiguous()
+    z = torch.zeros_like(r)
+    # loss-head kernels give the two population stds; the rest is the definition
+    sums = ops.loss_sums(z, z, z, z, z, r, z, 0)
+    r_mean, r_sq = (sums[7] / sums[11]).item(), (sums[10] / sums[11]).item()
+    sums_g = ops.loss_sums(z, z, z, z, z, g, z, 0)
+    g_mean, g_sq = (sums_g[7] / sums_g[11]).item(), (sums_g[10] / sums_g[11]).item()
+    r_std, g_std = max(r_sq - r_mean ** 2, 0.0) ** 0.5, max(g_sq - g_mean ** 2, 0.0) ** 0.5
+    ratio = torch.full((1,), alpha * g_std / r_std, device=r.device)
+    r_bal = ops.scale(_pad4(r), ratio)[: r.numel()]
+    g_bal = ops.add(g, r_bal.contiguous())
+    return g_bal.view(-1, 1), r_bal.view(-1, 1), alpha, r_std, g_std
+
+
+def _pad4(t):
+    n = (t.numel() + 3) // 4 * 4
+    if n == t.numel():
+        return t
+    out = torch.zeros(n, device=t.device)
+    out[: t.numel()] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discriminator, recognizer, style_promoter, composite_gan,
+               generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
+               batch_size, latent_dim, loss_fn, disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path,
+               fake_labels=None, nl=None, verbose=True, sync=True):
+    """One optimisation step (data_utils.py:358-473).
+
+    Extra keyword arguments (not in the reference): `fake_labels` overrides the host draw of :386-387
+    (parity tests, data-parallel ranks that received their shard from rank 0); `nl` maps pass names
+    ('G.style','G.up','D.fake','D.real','S.fake','S.style','S.real') to explicit NonLocalBlock
+    kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync.
+    """
+    G = composite_gan.generator
+    D, R, S = discriminator, recognizer, style_promoter
+    dev = G.device
+    red = G.reducer
+    nl = nl or {}
+
+    # ---- host RNG + shapes (:385-395); tf.random.normal `noise` is unused by the reference graph ----
+    if fake_labels is None:
+        random_bucket_idx, fake_labels = draw_fake_labels(random_words, bucket_size, batch_size)
+    images = _as_nhwc1(images, dev)
+    labels_t = _as_labels(labels, dev)
+    fake_t = _as_labels(fake_labels, dev)
+    if isinstance(my_imgs, (list, tuple)):
+        my_imgs = np.stack([np.asarray(m) for m in my_imgs], axis=0) if not torch.is_tensor(my_imgs[0]) else torch.stack(list(my_imgs), 0)
+    style = _as_nhwc1(my_imgs, dev)
+    if red.world_size > 1 and getattr(red, "shard_inputs", True):       # data parallel: this rank's slice of every per-step tensor
+        images, labels_t, fake_t, style = (red.shard(t) for t in (images, labels_t, fake_t, style))
+    L_r, L_f = labels_t.shape[1], fake_t.shape[1]
+
+    # ---- forward passes, all with the pre-update weights (:398-415) ----
+    x_f, ctx_g = G.forward(style, fake_t, nl.get("G.style"), nl.get("G.up"), training=True)
+    d_f, ctx_df = D.forward(x_f, nl.get("D.fake"))
+    s_f, ctx_sf = S.forward(x_f, nl.get("S.fake"))
+    r_f, ctx_rf = R.forward(x_f, fake_t, ctc_input_length(L_f), L_f, training=True)
+    d_r, ctx_dr = D.forward(images, nl.get("D.real"))
+    s_my, ctx_smy = S.forward(style, nl.get("S.style"))
+    s_r, _ = S.forward(images, nl.get("S.real"))
+    r_r, ctx_rr = R.forward(images, labels_t, ctc_input_length(L_r), L_r, training=True)
+
+    # ---- losses, gradient balancing, statistics and the upstream gradients of all four targets (:418-442) ----
+    mode = getattr(loss_fn, "mode", None)
+    if mode is None:
+        raise TypeError("loss_fn must be scrabble_gan_amd.net_loss.hinge or .not_saturating")
+    v = [t.reshape(-1) for t in (d_r, d_f, s_my, s_f, s_r)]
+    sums = red.all_reduce_sum(ops.loss_sums(*v, r_f, r_r, mode))
+    scalars, (gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r) = ops.loss_grads(*v, r_f, mode, bool(apply_gradient_balance), 1.0, sums)
+
+    # ---- backward sweeps against the same weight snapshot (:449-468) ----
+    for m in (D, R, S):
+        m.store.zero_grad()
+    discriminator.trainable = True
+    D.backward(ctx_dr, gD_r, want_dx=False, want_dw=True)
+    D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
+    recognizer.trainable = True
+    R.backward(ctx_rr, torch.ones_like(r_r), want_dx=False, want_dw=True)          # target r_real_logits: CTC on real only
+    style_promoter.trainable = True
+    S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
+    S.backward(ctx_sf, gS_f, want_dx=False, want_dw=True)
+    g_step = (batch_idx + 1) % disc_iters == 0
+    if g_step:
+        recognizer.trainable = False
+        discriminator.trainable = False
+        style_promoter.trainable = False
+        G.store.zero_grad()
+        dx = D.backward(ctx_df, gG_d, want_dx=True, want_dw=False)
+        ops.add(dx, S.backward(ctx_sf, gG_s, want_dx=True, want_dw=False), out=dx)
+        ops.add(dx, R.backward(ctx_rf, gG_r, want_dx=True, want_dw=False), out=dx)
+        G.backward(ctx_g, dx)
+
+    # ---- gradient exchange (data parallel: SUM, the targets are [B,1] vectors) + updates ----
+    for m in (D, R, S) + ((G,) if g_step else ()):
+        red.all_reduce_sum(m.store.grad)
+    discriminator_optimizer.apply_flat(D.store)
+    recognizer_optimizer.apply_flat(R.store)
+    stylepromoter_optimizer.apply_flat(S.store)
+    if g_step:
+        generator_optimizer.apply_flat(G.store)
+
+    if not sync:
+        return scalars
+    s = scalars.tolist()                                         # the one host sync of the step
+    if verbose:
+        print('>%d, %d/%d, d=%.3f, d_real=%.3f, d_fake=%.3f, g_trad=%.3f, r_loss_fake=%.3f, g_loss=%.3f, r=%.3f, s=%.3f' % (
+            epoch_idx + 1, batch_idx + 1, batch_per_epoch, s[6], s[7], s[8], s[3], s[0], s[9], s[1], s[14]))
+    return (s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], 1, s[11], s[12], s[13], s[14], s[15])
+
+
+# ------------------------------------------------------------------------------------------------
+SUMMARY_HEADER = ("disc_loss;disc_loss_real;disc_loss_fake;r_loss_real;r_loss_fake;r_loss_balanced;g_loss;g_lossT;g_lossS;"
+                  "g_loss_final;alpha;r_loss_fake_std;g_loss_std;s_loss;s_loss_real;s_loss_fake\n")
+
+
+def train(dataset, generator, discriminator, recognizer, style_promoter, composite_gan, checkpoint, checkpoint_prefix,
+          generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
+          seed_labels, buffer_size, batch_size, epochs, model_path, latent_dim, gen_path, loss_fn, disc_iters,
+          apply_gradient_balance, random_words, bucket_size, char_vector, max_batches_per_epoch=None):
+    """Epoch/batch loop, 16-column ';' summaries and per-epoch G/R weight saves (data_utils.py:198-352).
+    The summary rows carry the ';' the reference drops between g_loss_std and s_loss (Appendix C-10)."""
+    generator_save_dir = os.path.join(checkpoint_prefix, 'generator/')
+    recognizer_save_dir = os.path.join(checkpoint_prefix, 'recognizer/')
+    os.makedirs(generator_save_dir, exist_ok=True)
+    os.makedirs(recognizer_save_dir, exist_ok=True)
+    os.makedirs(gen_path, exist_ok=True)
+    batch_per_epoch = int(buffer_size / batch_size) + 1
+    if max_batches_per_epoch is not None:
+        batch_per_epoch = min(batch_per_epoch, max_batches_per_epoch)
+    print('no. training samples: ', buffer_size)
+    print('batch size:           ', batch_size)
+    print('no. batch_per_epoch:  ', batch_per_epoch)
+    print('epoch size:           ', epochs)
+    order = (6, 7, 8, 1, 0, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15)      # return tuple -> summary column order
+    with open(os.path.join(gen_path, "batch_summary.txt"), "w") as batch_summary, \
+            open(os.path.join(gen_path, "epoch_summary.txt"), "w") as epoch_summary:
+        epoch_summary.write(SUMMARY_HEADER)
+        batch_summary.write(SUMMARY_HEADER)
+        for epoch_idx in range(epochs):
+            start = time.time()
+            totals = [0.0] * 16
+            for batch_idx in range(batch_per_epoch):
+                image_batch, label_batch = next(dataset)
+                my_img_batch = random.choices(my_imgs, k=batch_size)
+                out = train_step(epoch_idx, batch_idx, batch_per_epoch, image_batch, label_batch, discriminator, recognizer,
+                                 style_promoter, composite_gan, generator_optimizer, discriminator_optimizer,
+                                 recognizer_optimizer, stylepromoter_optimizer, my_img_batch, batch_size, latent_dim, loss_fn,
+                                 disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path)
+                batch_summary.write(";".join(str(out[i]) for i in order) + "\n")
+                totals = [t + float(o) for t, o in zip(totals, out)]
+            epoch_summary.write(";".join(str(totals[i] / batch_per_epoch) for i in order) + "\n")
+            print('Time for epoch {} is {} sec'.format(epoch_idx + 1, time.time() - start))
+            generator.save_weights(os.path.join(generator_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
+            recognizer.save_weights(os.path.join(recognizer_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
+
+
+# ------------------------------------------------------------------------------------------------
+def synthetic_batch(batch_size: int, L_real: int, input_dim=(32, 160, 1), n_classes=52, seed=0):
+    """Synthetic inputs of SURVEY section 8(d): U(-1,1) images / style images, U{0..51} labels."""
+    rng = np.random.default_rng(seed)
+    h, w, c = input_dim
+    images = rng.uniform(-1, 1, (batch_size, h, 16 * L_real, c)).astype(np.float32)
+    labels = rng.integers(0, n_classes, (batch_size, L_real)).astype(np.int32)
+    my_imgs = rng.uniform(-1, 1, (batch_size, h, w, c)).astype(np.float32)
+    return images, labels, my_imgs
+
+
+def synthetic_random_words(bucket_size=10, words_per_bucket=1000, n_classes=52, seed=0):
+    rng = np.random.default_rng(seed + 1)
+    return [[list(map(int, rng.integers(0, n_classes, k + 1))) for _ in range(words_per_bucket)] for k in range(bucket_size)]

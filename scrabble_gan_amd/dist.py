@@ -1,0 +1,49 @@
+"""Data parallelism: one process per GPU, torch.distributed (backend 'nccl' = RCCL over xGMI on ROCm;
+'gloo' for the CPU tests).  The batch shards over ranks; the only exchanges are SUM all-reduces:
+the flat per-network gradient buffers (the reference differentiates [B,1] targets, i.e. sums over
+the batch: SURVEY fact 5), the 12 fp64 loss statistics, and the per-channel BN statistics (SyncBN)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+from .nn import Reducer
+
+
+class DistReducer(Reducer):
+    shard_inputs = True
+
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "call init_process_group first"
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def shard(self, t: torch.Tensor) -> torch.Tensor:
+        """This rank's contiguous slice [r*B/P, (r+1)*B/P) of a per-step batch tensor."""
+        B = t.shape[0]
+        if B % self.world_size:
+            raise ValueError("global batch %d is not divisible by world size %d" % (B, self.world_size))
+        b = B // self.world_size
+        return t[self.rank * b:(self.rank + 1) * b].contiguous()
+
+
+def init_from_env(backend: str = "nccl") -> "Reducer":
+    """Build the reducer from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return Reducer()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return DistReducer()

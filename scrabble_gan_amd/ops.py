@@ -15,6 +15,58 @@ RELU_IN, ACCUM, RELU_OUT, TANH_OUT = 1, 2, 4, 8
 BN_EPS = 1e-3
 
 
+class KernelTimer:
+    """HIP-event timing of kernel families on the stream the kernels are launched on (bench.py's
+    roofline leg).  `flops` is the algorithmic 2*M*N*K of the launch."""
+
+    def __init__(self):
+        self.records = {}
+
+    class _Region:
+        def __init__(self, timer, family, flops):
+            self.t, self.family, self.flops = timer, family, flops
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+        def __exit__(self, *exc):
+            self.b.record(torch.cuda.current_stream())
+            self.t.records.setdefault(self.family, []).append((self.a, self.b, self.flops))
+
+    def region(self, family, flops):
+        return KernelTimer._Region(self, family, flops)
+
+    def summary(self):
+        """{family: {launches, ms, tflops}} after a device synchronize."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[fam] = {"launches": len(recs), "ms": ms, "flops": fl, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+PROFILER: Optional[KernelTimer] = None
+
+
+def _timed(family: str, flops: float, thin: bool):
+    if PROFILER is None:
+        return _NULL
+    return PROFILER.region(family + ("_thin" if thin else ""), flops)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -50,8 +102,9 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     Ho, Wo = (H, W) if same else (H - kh + 1, W - kw + 1)
     if out is None:
         out = empty(B, Ho, Wo, Cout, like=x)
-    call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
-         _flags(relu_in, accum, relu_out, tanh_out), _stream())
+    with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+        call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+             _flags(relu_in, accum, relu_out, tanh_out), _stream())
     return out
 
 
@@ -63,8 +116,9 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     assert dy.shape[3] == Cout
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
-         _flags(accum=accum), _stream())
+    with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+        call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+             _flags(accum=accum), _stream())
     return out
 
 
@@ -73,7 +127,8 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False):
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
-    call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
+    with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
 
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
@@ -84,8 +139,9 @@ def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, a
     sh, sw = stride
     if out is None:
         out = empty(B, sh * H, sw * W, Cout, like=x)
-    call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
-         _flags(accum=accum), _stream())
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+        call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+             _flags(accum=accum), _stream())
     return out
 
 
@@ -97,8 +153,9 @@ def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=F
     H, W = Hs // sh, Ws // sw
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
-         _flags(accum=accum), _stream())
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+        call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+             _flags(accum=accum), _stream())
     return out
 
 
@@ -108,7 +165,8 @@ def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
     kh, kw, Cout, wc = dw.shape
     assert wc == Cin
     sh, sw = stride
-    call("sg_conv2d_transpose_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, 0, _stream())
+    with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+        call("sg_conv2d_transpose_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, 0, _stream())
 
 
 def bias_grad(dy, db):
@@ -393,4 +451,12 @@ def spectral_norm(w, u, power_iteration=1):
     out = torch.empty_like(w)
     ws = empty(lib().sg_spectral_norm_workspace_floats(K, N), like=w)
     call("sg_spectral_norm", _p(w), _p(u), _p(out), _p(ws), K, N, int(power_iteration), _stream())
+    return out
+
+
+def loss_terms(d_r, d_f, s_my, s_f, s_r, mode: int):
+    _chk(d_r, d_f, s_my, s_f, s_r)
+    B = d_r.numel()
+    out = empty(7, B, like=d_r)
+    call("sg_loss_terms", _p(d_r), _p(d_f), _p(s_my), _p(s_f), _p(s_r), B, mode, _p(out), _stream())
     return out

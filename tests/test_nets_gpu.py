@@ -1,0 +1,212 @@
+"""GPU parity of whole networks and of one full train_step against the CPU oracle (fp64) on
+identical explicit weights and inputs ('parity is defined on identical explicit
+weights and inputs'; the TF reference itself cannot run offline -> parity unpinned by the reference).
+
+Tolerance: fp32 kernels vs the fp64 oracle; max|gpu-ref| <= tol * max|ref| per tensor, tol = 1e-4
+for activations/logits/losses and 1e-3 for gradients and post-Adam weight deltas (deep fp32 chains,
+atomically accumulated weight gradients)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
+
+
+def close(got, ref, tol, name="", atol=0.0):
+    """max|got-ref| <= tol*max|ref| + atol.  `atol` is given as 1e-5 x the largest gradient of the net for
+    gradient tensors whose true value is ~0 (e.g. a bias feeding a BatchNorm: analytically zero)."""
+    got = got.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), name
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-12
+    assert err <= tol * scale + atol, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e, atol %.1e)" % (name, err, scale, err / scale, tol, atol)
+
+
+def net_atol(grads):
+    return 1e-5 * max(v.abs().max().item() for v in grads if v is not None)
+
+
+def perturb(model, gen, sigma=0.3):
+    """Make biases / BN affine / sigma non-trivial so every path carries signal."""
+    w = model.store.export()
+    for k, v in w.items():
+        if k.endswith(".sigma"):
+            w[k] = torch.tensor(sigma)
+        elif k.endswith(".b") or k.endswith(".beta"):
+            w[k] = torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".gamma"):
+            w[k] = 1 + torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".mm"):
+            w[k] = torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".mv"):
+            w[k] = 1 + torch.rand(v.shape, generator=gen) * 0.2
+    model.store.load(w)
+    return {k: v.double() for k, v in w.items()}
+
+
+def leaves(P):
+    out = {}
+    for k in P:
+        if O.is_trainable(k):
+            P[k] = P[k].clone().requires_grad_(True)
+            out[k] = P[k]
+    return out
+
+
+def nl_pair(C, gen, dev):
+    o = O.init_nonlocal(C, gen)
+    return o, {k: v.float().to(dev).contiguous() for k, v in o.items()}
+
+
+@pytest.fixture()
+def setup(dev):
+    from scrabble_gan_amd import net_architecture as NA
+    NA.configure(device=dev, seed=3)
+    return NA
+
+
+def test_discriminator(setup, dev):
+    NA = setup
+    gen = torch.Generator().manual_seed(5)
+    D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+    P = perturb(D, gen)
+    B, W = 2, 48
+    x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    nlo, nlg = nl_pair(64, gen, dev)
+    up = torch.randn(B, generator=gen, dtype=torch.float64)
+    lv = leaves(P)
+    xr = x.clone().requires_grad_(True)
+    ref = O.discriminator(xr, P, nlo)
+    (ref[:, 0] * up).sum().backward()
+    logits, ctx = D.forward(x.float().to(dev), nlg)
+    close(logits, ref, 1e-4, "logits")
+    D.store.zero_grad()
+    dx = D.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+    close(dx, xr.grad, 1e-3, "dx")
+    at = net_atol([v.grad for v in lv.values()])
+    for k, v in lv.items():
+        close(D.store.g[k], v.grad, 1e-3, "grad " + k, at)
+
+
+def test_recognizer(setup, dev):
+    NA = setup
+    gen = torch.Generator().manual_seed(6)
+    R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+    P = perturb(R, gen)
+    B, L = 3, 3
+    x = torch.rand(B, 32, 16 * L, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    labels = torch.randint(0, 52, (B, L), generator=gen)
+    up = torch.rand(B, generator=gen, dtype=torch.float64) + 0.5
+    for bn_training in (False, True):
+        Pc = {k: v.clone() for k, v in P.items()}
+        lv = leaves(Pc)
+        xr = x.clone().requires_grad_(True)
+        ref = O.recognizer(xr, labels, 4 * L - 1, L, Pc, bn_training=bn_training)
+        (ref[:, 0] * up).sum().backward()
+        R.trainable = bn_training
+        R.store.load({k: v for k, v in P.items() if k.endswith((".mm", ".mv"))})
+        loss, ctx = R.forward(x.float().to(dev), labels.int().to(dev), 4 * L - 1, L, training=True)
+        close(loss, ref[:, 0], 1e-4, "ctc cost bn_training=%s" % bn_training)
+        R.store.zero_grad()
+        dx = R.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+        # dx crosses 4 max-pools and 7 ReLU masks: a near-tie resolved differently in fp32 moves single pixels
+        close(dx, xr.grad, 5e-3, "dx")
+        at = net_atol([v.grad for v in lv.values()])
+        for k, v in lv.items():
+            close(R.store.g[k], v.grad, 2e-3, "grad %s bn_training=%s" % (k, bn_training), at)
+
+
+def test_generator(setup, dev):
+    NA = setup
+    gen = torch.Generator().manual_seed(7)
+    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+    P = perturb(G, gen)
+    B, L = 2, 2
+    style = torch.rand(B, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    y = torch.randint(0, 52, (B, L), generator=gen)
+    nls_o, nls_g = nl_pair(64, gen, dev)
+    nlu_o, nlu_g = nl_pair(64, gen, dev)
+    dimg = torch.randn(B, 32, 16 * L, 1, generator=gen, dtype=torch.float64)
+    lv = leaves(P)
+    stats = {}
+    ref = O.generator(style, y, P, nls_o, nlu_o, bn_stats=stats)
+    (ref * dimg).sum().backward()
+    img, ctx = G.forward(style.float().to(dev), y.int().to(dev), nls_g, nlu_g, training=True)
+    close(img, ref, 1e-4, "image")
+    G.store.zero_grad()
+    G.backward(ctx, dimg.float().to(dev))
+    at = net_atol([v.grad for v in lv.values()])
+    for k, v in lv.items():
+        close(G.store.g[k], v.grad, 2e-3, "grad " + k, at)
+    # moving statistics advanced once (momentum 0.99, Bessel-corrected variance)
+    st = stats["B1.cbn1"]
+    n = st["count"]
+    close(G.store.p["B1.cbn1.mm"], 0.99 * P["B1.cbn1.mm"] + 0.01 * st["mean"], 1e-4, "moving mean")
+    close(G.store.p["B1.cbn1.mv"], 0.99 * P["B1.cbn1.mv"] + 0.01 * st["var"] * n / (n - 1), 1e-4, "moving var")
+
+
+@pytest.mark.parametrize("loss_name,balance", [("hinge", False), ("not_saturating", True)])
+def test_train_step(setup, dev, loss_name, balance):
+    NA = setup
+    from scrabble_gan_amd import data_utils as DU, net_loss, optimizers
+    gen = torch.Generator().manual_seed(8)
+    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+    D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+    R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+    S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+    gan = NA.make_gan(G, D, R, S, vis_model=False)
+    Pg, Pd, Pr, Ps = (perturb(m, gen) for m in (G, D, R, S))
+    B, L_r, L_f = 2, 2, 3
+    images = torch.rand(B, 32, 16 * L_r, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    style = torch.rand(B, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    labels = torch.randint(0, 52, (B, L_r), generator=gen)
+    fake = torch.randint(0, 52, (B, L_f), generator=gen)
+    names = ["G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real"]
+    nlo, nlg = {}, {}
+    for n in names:
+        nlo[n], nlg[n] = nl_pair(64, gen, dev)
+    opt = {"G": {}, "D": {}, "R": {}, "S": {}}
+    loss_o = O.hinge if loss_name == "hinge" else O.not_saturating
+    ref_scalars, ref_grads, ref_img = O.train_step(images, labels, style, fake, Pg, Pd, Ps, Pr, nlo, opt, loss_fn=loss_o,
+                                                   apply_gradient_balance=balance)
+    opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+    out = DU.train_step(0, 0, 1, images.float().numpy(), labels.numpy().astype(np.int32), D, R, S, gan, opts[0], opts[1], opts[2],
+                        opts[3], style.float().numpy(), B, 128, getattr(net_loss, loss_name), 1, int(balance), None, 10, "",
+                        fake_labels=fake.numpy().astype(np.int32), nl=nlg, verbose=False)
+    assert len(out) == 16 and out[10] == 1
+    for i, (a, b) in enumerate(zip(out, ref_scalars)):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), "scalar %d: %r vs %r" % (i, a, b)
+    # gradients of all four nets
+    for net, model in (("D", D), ("R", R), ("S", S), ("G", G)):
+        at = net_atol(list(ref_grads[net].values()))
+        for k, v in ref_grads[net].items():
+            close(model.store.g[k], v, 2e-3, "%s grad %s" % (net, k), at)
+    # post-Adam weights: compare the update delta (first Adam step with beta_1 = 0 is ~ lr * sign(g))
+    # (elements whose gradient is below 1e-3 of the tensor's max are excluded: there the update is
+    #  lr * g / (|g| + eps/sqrt(1-beta_2)) and amplifies fp32 rounding of g itself)
+    for net, model, P1 in (("D", D, Pd), ("R", R, Pr), ("S", S, Ps), ("G", G, Pg)):
+        for k in model.store.trainable_names():
+            got, ref = model.store.p[k].detach().double().cpu(), P1[k].double()
+            gr = ref_grads[net][k].double()
+            mask = gr.abs() > 1e-3 * gr.abs().max()
+            assert ((got - ref).abs() * mask).max().item() <= 2e-6, "%s weight %s after Adam" % (net, k)
+            assert (got - ref).abs().max().item() <= 4.1e-4, "%s weight %s moved more than 2*lr" % (net, k)
+    # trainable flags as left by the reference (:464-466)
+    assert not D.trainable and not R.trainable and not S.trainable
+
+
+def test_fake_label_draw_is_the_reference_sequence():
+    from scrabble_gan_amd import data_utils as DU
+    words = DU.synthetic_random_words(10, 50)
+    random.seed(0)
+    idx, fl = DU.draw_fake_labels(words, 10, 4)
+    random.seed(0)
+    idx2 = random.randint(0, 9)
+    fl2 = np.array([random.choice(words[idx2]) for _ in range(4)], np.int32)
+    assert idx == idx2 and (fl == fl2).all() and fl.shape == (4, idx + 1)

@@ -1,0 +1,128 @@
+"""CPU-only checks of the host logic: the C-ABI library loads and exports every symbol the header
+declares (no compute calls without a GPU), the gin reader, the label/index bookkeeping (bit-exact),
+and the API surface of the reference (names, arity)."""
+import inspect
+import os
+import random
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from scrabble_gan_amd import _lib
+    decls = _lib.parse_header()
+    assert len(decls) >= 40
+    lib = _lib.lib()
+    for name in decls:
+        assert hasattr(lib, name), name
+    for must in ("sg_conv2d_fwd", "sg_conv2d_bwd_data", "sg_conv2d_bwd_weight", "sg_conv2d_transpose_fwd", "sg_bn_apply",
+                 "sg_attention_fwd", "sg_filterbank_fwd", "sg_softmax_ctc", "sg_adam_update", "sg_spectral_norm", "sg_loss_grads"):
+        assert must in decls
+    # pure host helpers may be called without a GPU
+    assert lib.sg_spectral_norm_workspace_floats(9216, 1024) == 9216 + 1024 + 4
+    assert lib.sg_bn_stats_workspace_floats(4096, 64) == 2 * 2 * 64
+
+
+def test_ops_fail_loudly_without_library(monkeypatch, tmp_path):
+    from scrabble_gan_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(_lib.ScrabbleHipError):
+        _lib.lib()
+
+
+def test_gin_reader_parses_the_config_surface():
+    from scrabble_gan_amd import gin_config as gin, main as M
+    gin.clear_config()
+    gin.parse_config_file(os.path.join(ROOT, "configs", "scrabble_gan_mi355x.gin"))
+    epochs, batch_size, latent_dim, embed_y, num_gen, kernel_reg, g_att, d_att, my_rec, my_disc = M.get_shared_specs()
+    assert (epochs, batch_size, latent_dim, embed_y, num_gen, g_att, d_att, my_rec, my_disc) == (10, 16, 128, (32, 8192), 16, 'B3', 'B1', 0, 0)
+    assert kernel_reg.__name__ == "spectral_norm"
+    in_dim, buf_size, n_classes, seq_len, bucket_size, ckpt, gen_path, m_path, raw_dir, read_dir, char_vec = M.setup_io()
+    assert in_dim == (32, 160, 1) and buf_size == 80377 and n_classes == 52 and seq_len is None and bucket_size == 10
+    assert char_vec == 'abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ' and ckpt.endswith('checkpoints/')
+    g_opt, d_opt, r_opt, w_opt, loss_fn, disc_iters, bal = M.setup_optimizer()
+    assert g_opt.learning_rate == 2e-4 and g_opt.beta_1 == 0.0 and g_opt.beta_2 == 0.999 and g_opt.epsilon == 1e-7
+    assert loss_fn.__name__ == "hinge" and loss_fn.mode == 0 and disc_iters == 1 and bal == 0
+    gin.parse_config("setup_optimizer.rmsprop = 1   # trailing comment\nsetup_optimizer.loss_fn = @not_saturating\nio.base_path = 'a#b/'")
+    out = M.setup_optimizer()
+    assert type(out[2]).__name__ == "RMSprop" and out[4].mode == 1
+    assert gin.query_parameter("io.base_path") == "a#b/"
+    with pytest.raises(gin.GinError):
+        gin.parse_config("setup_optimizer.loss_fn = @nope")
+    with pytest.raises(gin.GinError):
+        gin.parse_config("this is not gin")
+    gin.clear_config()
+    with pytest.raises(gin.GinError):
+        M.get_shared_specs()
+
+
+def test_bookkeeping_is_bit_exact():
+    from scrabble_gan_amd import data_utils as DU
+    cv = 'abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
+    assert DU.encode_word("auto", cv) == [0, 20, 19, 14]                     # the reference's own example (data_utils.py:48)
+    assert DU.encode_word("Zz", cv) == [51, 25]
+    with pytest.raises(ValueError):
+        DU.encode_word("a-b", cv)
+    assert [DU.bucket_width((32, 160, 1), b) for b in (1, 4, 10, 23)] == [16, 64, 160, 368]
+    assert [DU.ctc_input_length(L) for L in (1, 10, 23)] == [3, 39, 91]
+    words = DU.bucket_words(["a\n", "to", "  cat ", "elephantine", "Dog"], 10, cv)
+    assert len(words) == 10 and words[0] == [[0]] and words[1] == [[19, 14]] and words[2] == [[2, 0, 19], [29, 14, 6]]
+    assert all(len(w) == k + 1 for k, b in enumerate(words) for w in b) and words[9] == []
+    img = np.array([[[0, 255], [127, 128]]], dtype=np.uint8).reshape(1, 2, 2)
+    out = DU.normalize_images(np.zeros((3, 32, 48), np.uint8), (32, 160, 1), 3)
+    assert out.shape == (3, 32, 48, 1) and out.dtype == np.float32 and (out == -1.0).all()
+    assert np.allclose((img.astype('float32') - 127.5) / 127.5, [[[-1, 1], [-0.5 / 127.5, 0.5 / 127.5]]])
+    # same `random` call sequence as data_utils.py:386-387
+    rw = DU.synthetic_random_words(10, 20)
+    random.seed(3)
+    idx, fl = DU.draw_fake_labels(rw, 10, 5)
+    random.seed(3)
+    idx2 = random.randint(0, 9)
+    fl2 = np.array([random.choice(rw[idx2]) for _ in range(5)], np.int32)
+    assert idx == idx2 and fl.dtype == np.int32 and (fl == fl2).all() and fl.shape == (5, idx + 1)
+
+
+def test_reference_api_surface():
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss
+    ref_params = ["epoch_idx", "batch_idx", "batch_per_epoch", "images", "labels", "discriminator", "recognizer", "style_promoter",
+                  "composite_gan", "generator_optimizer", "discriminator_optimizer", "recognizer_optimizer",
+                  "stylepromoter_optimizer", "my_imgs", "batch_size", "latent_dim", "loss_fn", "disc_iters",
+                  "apply_gradient_balance", "random_words", "bucket_size", "gen_path"]
+    assert list(inspect.signature(DU.train_step).parameters)[:22] == ref_params
+    assert list(inspect.signature(NA.make_generator).parameters) == ["latent_dim", "input_dim", "embed_y", "kernel_reg",
+                                                                    "blocks_with_attention", "vocab_size", "vis_model"]
+    assert list(inspect.signature(NA.make_discriminator).parameters) == ["input_dim", "kernel_reg", "blocks_with_attention", "vis_model"]
+    assert list(inspect.signature(NA.make_style_promoter).parameters) == ["input_dim", "kernel_reg", "blocks_with_attention", "vis_model"]
+    assert list(inspect.signature(NA.make_recognizer).parameters) == ["input_dim", "sequence_length", "output_classes", "vis_model"]
+    assert list(inspect.signature(NA.make_my_recognizer).parameters) == ["input_dim", "sequence_length", "output_classes", "vis_model"]
+    assert list(inspect.signature(NA.make_gan).parameters) == ["g_model", "d_model", "r_model", "w_model", "vis_model"]
+    assert NA.get_in_out_channels_gen(32) == ([512, 256, 128], [256, 128, 64])
+    assert NA.get_in_out_channels_disc(1, 32) == ([1, 64, 512, 1024], [64, 512, 1024, 1024])
+    with pytest.raises(ValueError, match="Unsupported resolution"):
+        NA.get_in_out_channels_gen(64)
+    with pytest.raises(ValueError, match="Unsupported color channels"):
+        NA.get_in_out_channels_disc(2, 32)
+    assert len(inspect.signature(net_loss.not_saturating).parameters) == 5
+    assert len(inspect.signature(net_loss.hinge).parameters) == 5        # 4 + the ignored 5th (Appendix C-1)
+
+
+def test_param_store_layout_on_cpu():
+    import torch
+    from scrabble_gan_amd import nn
+    specs = nn.block_down_specs("B1", 1, 64) + [("NL_B1.sigma", (), nn.zeros, True), ("bn.mm", (6,), nn.zeros, False)]
+    S = nn.ParamStore(specs, torch.device("cpu"), torch.Generator().manual_seed(0))
+    assert S.num_params() == 9 * 64 + 64 + 9 * 64 * 64 + 64 + 64 + 64 + 1
+    for k in S.trainable_names():
+        assert S.p[k].data_ptr() % 16 == 0 and S.g[k].shape == S.p[k].shape      # float4-aligned slices
+    w = S.p["B1.conv2.w"].reshape(-1, 64)
+    assert torch.allclose(w.t() @ w, torch.eye(64), atol=1e-5)                    # orthogonal init
+    S.g["B1.conv1.b"].fill_(2.0)
+    assert S.grad.sum().item() == 128.0
+    S.zero_grad()
+    assert S.grad.abs().sum().item() == 0.0

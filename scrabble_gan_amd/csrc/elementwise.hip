@@ -170,6 +170,38 @@ __global__ __launch_bounds__(256) void k_gap_bwd(const float* dout, const float*
 }
 
 // db[n] += sum_m dy[m,n].  Each workgroup reduces a slab of rows, then one float atomic per column.
+// float4 path (N % 4 == 0): CL column lanes x RL row lanes per workgroup, LDS tree over the row lanes
+__global__ __launch_bounds__(256) void k_bias_grad_v4(const float* dy, float* db, long M, int N, int rows_per_block) {
+  __shared__ float4 red[256];
+  const int cqn = N >> 2;
+  int CL = 256;
+  while (CL > cqn) CL >>= 1;             // largest power of two <= min(cqn, 256)
+  const int RL = 256 / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const long m0 = (long)blockIdx.x * rows_per_block;
+  const long m1 = min(M, m0 + rows_per_block);
+  for (int cg0 = 0; cg0 < cqn; cg0 += CL) {
+    const int cg = cg0 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cg < cqn)
+      for (long m = m0 + rl; m < m1; m += RL) s = f4add(s, CF4(dy + m * N + 4 * cg));
+    if (RL > 1) {
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int st = RL >> 1; st > 0; st >>= 1) {
+        if (rl < st) red[threadIdx.x] = f4add(red[threadIdx.x], red[threadIdx.x + st * CL]);
+        __syncthreads();
+      }
+      s = red[threadIdx.x];
+      __syncthreads();
+    }
+    if (rl == 0 && cg < cqn) {
+      float* d = db + 4 * cg;
+      atomicAdd(d + 0, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bias_grad(const float* dy, float* db, long M, int N, int rows_per_block) {
   __shared__ float red[256];
   const long m0 = (long)blockIdx.x * rows_per_block;
@@ -286,6 +318,11 @@ extern "C" int sg_gap_bwd(const float* dout, const float* x, float* dx, int B, i
 
 extern "C" int sg_bias_grad(const float* dy, float* db, long M, int N, void* stream) {
   if (!dy || !db || N < 1) return SG_ERR_ARG;
+  if ((N & 3) == 0 && ((uintptr_t)dy & 15) == 0) {
+    const int rpb = 512;
+    hipLaunchKernelGGL(k_bias_grad_v4, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
+    return sg_launch_status();
+  }
   const int rpb = 1024;
   hipLaunchKernelGGL(k_bias_grad, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
   return sg_launch_status();

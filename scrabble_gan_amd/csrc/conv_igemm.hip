@@ -24,6 +24,8 @@ __device__ __forceinline__ int sg_xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+#define SG_IDENT_OUT 32   // internal flag: output pixel == base-grid pixel (idx = m*N + n, no div/mod)
+
 template <int BM, int BN, int WM, int WN, bool B_NK>
 __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmArgs p) {
   constexpr int BK = SG_BK;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
   constexpr int BKN_P = BK / BKN_RPP;
   constexpr int BNK_P = BN * 8 / NT;        // [N,K] loader passes
   constexpr int B_P = B_NK ? BNK_P : BKN_P;
+  constexpr int KS = BK / 2;                // MFMA k-steps per k-tile
   static_assert(A_P >= 1 && B_P >= 1, "tile/thread mismatch");
 
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
@@ -58,68 +61,81 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
   const int KT = p.ntaps * kchunks;
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
 
-  // ---- per-thread A rows (fixed for the whole K loop) ----
+  // ---- per-thread operand rows: everything that does not depend on the k-tile is hoisted, so the
+  //      loop body is one add + one bit test per load and can hide between the MFMAs ----
   const int kc = tid & 7;
-  int a_y[A_P], a_x[A_P], a_pix[A_P];
-  bool a_ok[A_P];
+  const int row0 = tid >> 3;
+  int a_base[A_P];
+  unsigned a_mask[A_P];
 #pragma unroll
   for (int i = 0; i < A_P; ++i) {
-    const int r = (tid >> 3) + i * (NT / 8);
-    const int m = m0 + r;
-    a_ok[i] = m < M;
-    const int mm = a_ok[i] ? m : 0;
+    const int m = m0 + row0 + i * (NT / 8);
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
     const int b = mm / HW;
     const int rem = mm - b * HW;
     const int yg = rem / p.Wg;
     const int xg = rem - yg * p.Wg;
-    a_y[i] = yg * p.a_sy;
-    a_x[i] = xg * p.a_sx;
-    a_pix[i] = b * p.Ha * p.Wa;
+    const int y = yg * p.a_sy, x = xg * p.a_sx;
+    a_base[i] = ((b * p.Ha + y) * p.Wa + x) * p.Ca + 4 * kc;
+    unsigned mk = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy = y + p.taps[t].dy, ix = x + p.taps[t].dx;
+      if (ok && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) mk |= 1u << t;
+    }
+    a_mask[i] = mk;
+  }
+  int b_off[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    if (B_NK) {
+      const int n = n0 + row0 + i * (NT / 8);
+      b_ok[i] = n < p.N;
+      b_off[i] = n * p.ldw + 4 * kc;
+    } else {
+      const int k = tid / (BN / 4) + i * BKN_RPP;
+      const int n = n0 + 4 * (tid % (BN / 4));
+      b_ok[i] = n < p.N;
+      b_off[i] = k * p.ldw + n;
+    }
   }
 
   float4 a_reg[A_P];
   float4 b_reg[B_P];
+  int lt = 0, lc0 = 0;   // (tap, channel offset) of the next k-tile to fetch
 
-  auto load_tile = [&](int kt) {
-    const int t = kt / kchunks;
-    const int c0 = (kt - t * kchunks) * BK;
-    const int dy = p.taps[t].dy, dx = p.taps[t].dx;
-    const float* wt = p.w + p.taps[t].w_off;
-    const int ca = c0 + 4 * kc;
+  auto load_a = [&]() {
+    const int tap_off = (p.taps[lt].dy * p.Wa + p.taps[lt].dx) * p.Ca + lc0;
+    const bool cok = lc0 + 4 * kc < p.Ca;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-      const bool ok = a_ok[i] && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa && ca < p.Ca;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(p.a + (size_t)(a_pix[i] + iy * p.Wa + ix) * p.Ca + ca);
+      if (((a_mask[i] >> lt) & 1u) && cok) v = *reinterpret_cast<const float4*>(p.a + (a_base[i] + tap_off));
       a_reg[i] = v;
     }
-    if (B_NK) {
-#pragma unroll
-      for (int i = 0; i < B_P; ++i) {
-        const int n = n0 + (tid >> 3) + i * (NT / 8);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.N && ca < p.Ca) v = *reinterpret_cast<const float4*>(wt + (size_t)n * p.ldw + ca);
-        b_reg[i] = v;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_P; ++i) {
-        const int k = tid / (BN / 4) + i * BKN_RPP;
-        const int n = n0 + 4 * (tid % (BN / 4));
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + k < p.Ca && n < p.N) v = *reinterpret_cast<const float4*>(wt + (size_t)(c0 + k) * p.ldw + n);
-        b_reg[i] = v;
-      }
-    }
   };
-
-  auto store_tile = [&](int buf) {
+  auto load_b = [&]() {
+    const float* wt = p.w + p.taps[lt].w_off;
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_NK) {
+        if (b_ok[i] && lc0 + 4 * kc < p.Ca) v = *reinterpret_cast<const float4*>(wt + (b_off[i] + lc0));
+      } else {
+        const int k = tid / (BN / 4) + i * BKN_RPP;
+        if (b_ok[i] && lc0 + k < p.Ca) v = *reinterpret_cast<const float4*>(wt + (b_off[i] + lc0 * p.ldw));
+      }
+      b_reg[i] = v;
+    }
+    lc0 += BK;                       // advance the fetch cursor
+    if (lc0 >= p.Ca) { lc0 = 0; ++lt; }
+  };
+  auto store_a = [&](int buf) {
     float* as = As + buf * BK * LDA;
-    float* bs = Bs + buf * BK * LDB;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      const int r = (tid >> 3) + i * (NT / 8);
+      const int r = row0 + i * (NT / 8);
       float4 v = a_reg[i];
       if (relu_in) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -129,19 +145,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
       as[(4 * kc + 2) * LDA + r] = v.z;
       as[(4 * kc + 3) * LDA + r] = v.w;
     }
-    if (B_NK) {
+  };
+  auto store_b = [&](int buf) {
+    float* bs = Bs + buf * BK * LDB;
 #pragma unroll
-      for (int i = 0; i < B_P; ++i) {
-        const int r = (tid >> 3) + i * (NT / 8);
+    for (int i = 0; i < B_P; ++i) {
+      if (B_NK) {
+        const int r = row0 + i * (NT / 8);
         const float4 v = b_reg[i];
         bs[(4 * kc + 0) * LDB + r] = v.x;
         bs[(4 * kc + 1) * LDB + r] = v.y;
         bs[(4 * kc + 2) * LDB + r] = v.z;
         bs[(4 * kc + 3) * LDB + r] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_P; ++i) {
+      } else {
         const int k = tid / (BN / 4) + i * BKN_RPP;
         const int nn = 4 * (tid % (BN / 4));
         *reinterpret_cast<float4*>(bs + k * LDB + nn) = b_reg[i];
@@ -162,36 +178,52 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
   const int khalf = lane >> 5;
 
   if (KT > 0) {
-    load_tile(0);
-    store_tile(0);
+    load_a();
+    load_b();
+    store_a(0);
+    store_b(0);
   }
   __syncthreads();
 
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
+    const bool more = kt + 1 < KT;
     const float* as = As + buf * BK * LDA + khalf * LDA + a_col;
     const float* bs = Bs + buf * BK * LDB + khalf * LDB + b_col;
+    // The next k-tile's global loads are issued after the first MFMA groups and its LDS stores before
+    // the last ones, so address arithmetic, VMEM issue and LDS writes all sit in MFMA shadows
+    // (each 32x32x2 f32 MFMA leaves ~56 of its 64 cycles of vector issue free).
+    float af[2][TM], bf[2][TN];     // fragment double buffer: k-step kk+1 is read from LDS under the MFMAs of kk
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[0][i] = as[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = as[kk * 2 * LDA + i * 32];
+    for (int j = 0; j < TN; ++j) bf[0][j] = bs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = bs[kk * 2 * LDB + j * 32];
+    for (int kk = 0; kk < KS; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nxt][i] = as[(kk + 1) * 2 * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+      if (kk == 0 && more) load_a();
+      if (kk == 1 && more) load_b();
+      if (kk == KS - 5 && more) store_a(buf ^ 1);
+      if (kk == KS - 3 && more) store_b(buf ^ 1);
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue ----
   const bool accum = (p.flags & SG_ACCUM) != 0;
   const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
+  const bool ident = (p.flags & SG_IDENT_OUT) != 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -206,12 +238,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
         const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         const int m = m0 + row;
         if (m >= M) continue;
-        const int b = m / HW;
-        const int rem = m - b * HW;
-        const int yg = rem / p.Wg;
-        const int xg = rem - yg * p.Wg;
-        const size_t idx =
-            ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
+        size_t idx;
+        if (ident) {
+          idx = (size_t)m * p.N + n;
+        } else {
+          const int b = m / HW;
+          const int rem = m - b * HW;
+          const int yg = rem / p.Wg;
+          const int xg = rem - yg * p.Wg;
+          idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
+        }
         float v = acc[i][j][r] + bsum;
         if (p.mask && p.mask[idx] <= 0.f) v = 0.f;
         if (accum) v += p.out[idx];
@@ -223,7 +259,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
+static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
+  SgIgemmArgs a = a_in;
+  if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG_IDENT_OUT;
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int grid = sg_cdiv(M, BM) * sg_cdiv(a.N, BN);
   if (grid <= 0) return SG_OK;

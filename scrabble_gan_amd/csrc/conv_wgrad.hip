@@ -41,43 +41,64 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_wgrad_kernel(const SgWgradA
   float4 p_reg[P_P], q_reg[Q_P];
   const int pc = c0 + 4 * (tid % (BC / 4));
   const int qn = n0 + 4 * (tid % (BN / 4));
+  const bool p_cok = pc < p.Cp, q_cok = qn < p.Cq;
+  constexpr int KS = BK / 2;
 
-  auto load_tile = [&](int kt) {
+  // Per-slot pixel cursors (b, yg, xg), decoded once and advanced by BK pixels per k-tile with
+  // compare/subtract wraps: no integer division inside the loop.
+  int pb[P_P], py[P_P], px[P_P], qb[Q_P], qy[Q_P], qx[Q_P];
+  auto decode = [&](int m, int& bb, int& yy, int& xx) {
+    bb = m / HW;
+    const int rem = m - bb * HW;
+    yy = rem / p.Wg;
+    xx = rem - yy * p.Wg;
+  };
+#pragma unroll
+  for (int i = 0; i < P_P; ++i) decode(m_begin + tid / (BC / 4) + i * P_RPP, pb[i], py[i], px[i]);
+#pragma unroll
+  for (int i = 0; i < Q_P; ++i) decode(m_begin + tid / (BN / 4) + i * Q_RPP, qb[i], qy[i], qx[i]);
+  int m_next = m_begin;          // first pixel of the next k-tile to fetch
+  auto advance = [&](int& bb, int& yy, int& xx) {
+    xx += BK;
+    while (xx >= p.Wg) { xx -= p.Wg; ++yy; }
+    while (yy >= p.Hg) { yy -= p.Hg; ++bb; }
+  };
+
+  auto load_p = [&]() {
 #pragma unroll
     for (int i = 0; i < P_P; ++i) {
-      const int m = m_begin + kt * BK + tid / (BC / 4) + i * P_RPP;
+      const int m = m_next + tid / (BC / 4) + i * P_RPP;
+      const int iy = py[i] * p.p_sy + dy, ix = px[i] * p.p_sx + dx;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end && pc < p.Cp) {
-        const int b = m / HW, rem = m - b * HW;
-        const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
-        const int iy = yg * p.p_sy + dy, ix = xg * p.p_sx + dx;
-        if (iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp)
-          v = *reinterpret_cast<const float4*>(p.p + ((size_t)(b * p.Hp + iy) * p.Wp + ix) * p.Cp + pc);
-      }
+      if (m < m_end && p_cok && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp)
+        v = *reinterpret_cast<const float4*>(p.p + (((pb[i] * p.Hp + iy) * p.Wp + ix) * p.Cp + pc));
       p_reg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < Q_P; ++i) {
-      const int m = m_begin + kt * BK + tid / (BN / 4) + i * Q_RPP;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end && qn < p.Cq) {
-        const int b = m / HW, rem = m - b * HW;
-        const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
-        v = *reinterpret_cast<const float4*>(
-            p.q + ((size_t)(b * p.Hq + yg * p.q_sy) * p.Wq + xg * p.q_sx) * p.Cq + qn);
-      }
-      q_reg[i] = v;
+      advance(pb[i], py[i], px[i]);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto load_q = [&]() {
+#pragma unroll
+    for (int i = 0; i < Q_P; ++i) {
+      const int m = m_next + tid / (BN / 4) + i * Q_RPP;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end && q_cok)
+        v = *reinterpret_cast<const float4*>(p.q + (((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn));
+      q_reg[i] = v;
+      advance(qb[i], qy[i], qx[i]);
+    }
+    m_next += BK;
+  };
+  auto store_p = [&](int buf) {
     float* ps = Ps + buf * BK * BC;
-    float* qs = Qs + buf * BK * BN;
 #pragma unroll
     for (int i = 0; i < P_P; ++i) {
       float4 v = p_reg[i];
       if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       *reinterpret_cast<float4*>(ps + (tid / (BC / 4) + i * P_RPP) * BC + 4 * (tid % (BC / 4))) = v;
     }
+  };
+  auto store_q = [&](int buf) {
+    float* qs = Qs + buf * BK * BN;
 #pragma unroll
     for (int i = 0; i < Q_P; ++i)
       *reinterpret_cast<float4*>(qs + (tid / (BN / 4) + i * Q_RPP) * BN + 4 * (tid % (BN / 4))) = q_reg[i];
@@ -96,29 +117,42 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_wgrad_kernel(const SgWgradA
   const int b_col = wn * (BN / WN) + (lane & 31);
 
   if (KT > 0) {
-    load_tile(0);
-    store_tile(0);
+    load_p();
+    load_q();
+    store_p(0);
+    store_q(0);
   }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
+    const bool more = kt + 1 < KT;
     const float* ps = Ps + buf * BK * BC + khalf * BC + a_col;
     const float* qs = Qs + buf * BK * BN + khalf * BN + b_col;
+    float af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[0][i] = ps[i * 32];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ps[kk * 2 * BC + i * 32];
+    for (int j = 0; j < TN; ++j) bf[0][j] = qs[j * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = qs[kk * 2 * BN + j * 32];
+    for (int kk = 0; kk < KS; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nxt][i] = ps[(kk + 1) * 2 * BC + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = qs[(kk + 1) * 2 * BN + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+      // next k-tile: global loads right after the first MFMA groups, LDS stores before the last ones
+      if (kk == 0 && more) load_p();
+      if (kk == 1 && more) load_q();
+      if (kk == KS - 5 && more) store_p(buf ^ 1);
+      if (kk == KS - 3 && more) store_q(buf ^ 1);
     }
-    if (kt + 1 < KT) store_tile(buf ^ 1);
     __syncthreads();
   }
 

@@ -132,6 +132,23 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         images, labels_t, fake_t, style = (red.shard(t) for t in (images, labels_t, fake_t, style))
     L_r, L_f = labels_t.shape[1], fake_t.shape[1]
 
+    # NonLocalBlock re-draws its four 1x1 kernels on every call.  Draw all seven sets of this
+    # step now -- same generators, same order as the per-call draws -- with one async upload, so no forward pass
+    # stalls the launch queue on a host->device copy.
+    if G.nl_mode == "reference":
+        order = [("G.style", G, G.trunk.attn), ("G.up", G, G.up_attn), ("D.fake", D, D.trunk.attn), ("S.fake", S, S.trunk.attn),
+                 ("D.real", D, D.trunk.attn), ("S.style", S, S.trunk.attn), ("S.real", S, S.trunk.attn)]
+        def chan(m, attn, up):
+            return m.out_ch[m.up_names.index(attn[0])] if up else m.trunk.cout[m.trunk.names.index(attn[0])]
+        # (passes with several attention blocks keep the per-call draw inside forward)
+        todo = [(name, m, chan(m, attn, name == "G.up")) for name, m, attn in order if len(attn) == 1 and name not in nl]
+        if todo:
+            from .nn import nonlocal_weights_batch
+            drawn = nonlocal_weights_batch([(c, m.nl_gen) for _, m, c in todo], dev)
+            todo = [(name, m) for name, m, _ in todo]
+            nl = dict(nl)
+            nl.update({name: d for (name, _), d in zip(todo, drawn)})
+
     # ---- forward passes, all with the pre-update weights (:398-415) ----
     x_f, ctx_g = G.forward(style, fake_t, nl.get("G.style"), nl.get("G.up"), training=True)
     d_f, ctx_df = D.forward(x_f, nl.get("D.fake"))

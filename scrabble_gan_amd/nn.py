@@ -171,6 +171,32 @@ def nonlocal_weights(C: int, gen: torch.Generator, device) -> Dict[str, torch.Te
             "g": orthogonal((1, 1, C, C // 2), gen).to(device), "o": orthogonal((1, 1, C // 2, C), gen).to(device)}
 
 
+def nonlocal_weights_batch(requests, device) -> List[Dict[str, torch.Tensor]]:
+    """Draw the kernels of several NonLocalBlock calls at once: QR on the host, ONE pinned staging buffer and
+    ONE asynchronous H2D copy, so the per-call re-draw of the reference (fact 3) costs no mid-step host sync.
+    `requests` = [(C, generator), ...]."""
+    host, shapes = [], []
+    for C, gen in requests:
+        for k, shp in (("theta", (1, 1, C, C // 8)), ("phi", (1, 1, C, C // 8)), ("g", (1, 1, C, C // 2)), ("o", (1, 1, C // 2, C))):
+            host.append(orthogonal(shp, gen).reshape(-1))
+            shapes.append((k, shp))
+    flat = torch.cat(host)
+    if device.type == "cuda":
+        flat = flat.pin_memory()
+    dev = flat.to(device, non_blocking=True)
+    out, off, idx = [], 0, 0
+    for _ in requests:
+        d = {}
+        for _k in range(4):
+            k, shp = shapes[idx]
+            n = int(math.prod(shp))
+            d[k] = dev[off:off + n].view(shp)
+            off += n
+            idx += 1
+        out.append(d)
+    return out
+
+
 def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor):
     B, H, W, C = x.shape
     w_t, w_p, w_g, w_o = (nlw[k].view(1, 1, *nlw[k].shape[-2:]) for k in ("theta", "phi", "g", "o"))

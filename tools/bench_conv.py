@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default=None)
     ap.add_argument("--filter", default=None)
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS probe: same cycles, higher clock)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -50,6 +51,8 @@ def main():
         x = torch.randn(B, H, W, Ci, device=dev)
         w = torch.randn(k, k, Ci, Co, device=dev) * 0.05
         dy = torch.randn(B, H, W, Co, device=dev)
+        if args.zeros:
+            x.zero_(); w.zero_(); dy.zero_()
         y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.zeros_like(w)
         flops = 2.0 * B * H * W * k * k * Ci * Co
         res = {}

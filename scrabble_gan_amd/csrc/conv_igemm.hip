@@ -12,6 +12,7 @@
 //   epilogue         : bias(+bias2), ReLU-backward mask, accumulate, ReLU, straight from the
 //                      accumulators (lanes 0-31 of a register write one 128-byte row segment)
 #include "sg_conv.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -26,17 +27,17 @@ __device__ __forceinline__ int sg_xcd_remap(int orig, int nwg) {
 
 #define SG_IDENT_OUT 32   // internal flag: output pixel == base-grid pixel (idx = m*N + n, no div/mod)
 
-template <int BM, int BN, int WM, int WN, bool B_NK>
-__global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmArgs p) {
-  constexpr int BK = SG_BK;
+template <int BM, int BN, int WM, int WN, bool B_NK, int BK, int OCC>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgemmArgs p) {
   constexpr int NT = WM * WN * 64;
+  constexpr int KQ = BK / 4;                // float4 chunks per operand row in a k-tile
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDA = BM + 1;
   constexpr int LDB = B_NK ? BN + 1 : BN;
-  constexpr int A_P = BM * 8 / NT;          // float4 loads of A per thread per k-tile
+  constexpr int A_P = BM * KQ / NT;         // float4 loads of A per thread per k-tile
   constexpr int BKN_RPP = NT / (BN / 4);    // B rows covered per pass ([K,N] loader)
   constexpr int BKN_P = BK / BKN_RPP;
-  constexpr int BNK_P = BN * 8 / NT;        // [N,K] loader passes
+  constexpr int BNK_P = BN * KQ / NT;       // [N,K] loader passes
   constexpr int B_P = B_NK ? BNK_P : BKN_P;
   constexpr int KS = BK / 2;                // MFMA k-steps per k-tile
   static_assert(A_P >= 1 && B_P >= 1, "tile/thread mismatch");
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
 
   // ---- per-thread operand rows: everything that does not depend on the k-tile is hoisted, so the
   //      loop body is one add + one bit test per load and can hide between the MFMAs ----
-  const int kc = tid & 7;
-  const int row0 = tid >> 3;
+  const int kc = tid % KQ;
+  const int row0 = tid / KQ;
   int a_base[A_P];
   unsigned a_mask[A_P];
 #pragma unroll
   for (int i = 0; i < A_P; ++i) {
-    const int m = m0 + row0 + i * (NT / 8);
+    const int m = m0 + row0 + i * (NT / KQ);
     const bool ok = m < M;
     const int mm = ok ? m : 0;
     const int b = mm / HW;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
 #pragma unroll
   for (int i = 0; i < B_P; ++i) {
     if (B_NK) {
-      const int n = n0 + row0 + i * (NT / 8);
+      const int n = n0 + row0 + i * (NT / KQ);
       b_ok[i] = n < p.N;
       b_off[i] = n * p.ldw + 4 * kc;
     } else {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
     float* as = As + buf * BK * LDA;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      const int r = row0 + i * (NT / 8);
+      const int r = row0 + i * (NT / KQ);
       float4 v = a_reg[i];
       if (relu_in) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       if (B_NK) {
-        const int r = row0 + i * (NT / 8);
+        const int r = row0 + i * (NT / KQ);
         const float4 v = b_reg[i];
         bs[(4 * kc + 0) * LDB + r] = v.x;
         bs[(4 * kc + 1) * LDB + r] = v.y;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_igemm_kernel(const SgIgemmA
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = SG_BK, int OCC = 2>
 static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   SgIgemmArgs a = a_in;
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG_IDENT_OUT;
@@ -266,9 +267,9 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   const int grid = sg_cdiv(M, BM) * sg_cdiv(a.N, BN);
   if (grid <= 0) return SG_OK;
   if (b_nk)
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
   else
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
   return sg_launch_status();
 }
 
@@ -277,8 +278,20 @@ int sg_launch_igemm(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
   if (a.ntaps < 0 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
   if ((long)a.Bn * a.Ha * a.Wa * a.Ca >= (1L << 31) || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31))
     return SG_ERR_ARG;  // 32-bit pixel indexing inside the kernel
-  if (a.N > 64) return launch_cfg<128, 128, 2, 2>(a, b_nk, s);
-  if (a.N > 32) return launch_cfg<128, 64, 2, 2>(a, b_nk, s);
+  static const int bk_env = getenv("SG_IGEMM_BK") ? atoi(getenv("SG_IGEMM_BK")) : 16;   // tuning knobs
+  static const int tile_env = getenv("SG_IGEMM_TILE") ? atoi(getenv("SG_IGEMM_TILE")) : 0;
+  if (a.N > 64) {
+    // tile choice: 128x128 unless its grid leaves the 256 CUs badly balanced (few tiles per CU with a
+    // large fractional remainder); 128x64 then doubles the tile count at a small efficiency cost
+    const long M = (long)a.Bn * a.Hg * a.Wg;
+    const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(a.N, 128), t64 = (long)sg_cdiv(M, 128) * sg_cdiv(a.N, 64);
+    const double e128 = (double)t128 / (((t128 + 255) / 256) * 256.0);
+    const double e64 = 0.93 * (double)t64 / (((t64 + 255) / 256) * 256.0);
+    const bool narrow = tile_env == 64 || (tile_env == 0 && t128 < 2048 && e64 > e128);
+    if (narrow) return bk_env == 16 ? launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s) : launch_cfg<128, 64, 2, 2>(a, b_nk, s);
+    return bk_env == 16 ? launch_cfg<128, 128, 2, 2, 16, 3>(a, b_nk, s) : launch_cfg<128, 128, 2, 2>(a, b_nk, s);
+  }
+  if (a.N > 32) return bk_env == 16 ? launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s) : launch_cfg<128, 64, 2, 2>(a, b_nk, s);
   return launch_cfg<128, 32, 4, 1>(a, b_nk, s);
 }
 

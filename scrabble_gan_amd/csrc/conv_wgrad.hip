@@ -7,12 +7,12 @@
 // that re-read one activation slab run together and hit L2/Infinity Cache.  Partial sums are
 // added to dW with float atomics (one 128-byte row segment per half-wave: full atomic rate).
 #include "sg_conv.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BC, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64, 2) void sg_wgrad_kernel(const SgWgradArgs p) {
-  constexpr int BK = 32;
+template <int BC, int BN, int WM, int WN, int BK, int OCC>
+__global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgradArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
   constexpr int P_RPP = NT / (BC / 4), P_P = BK / P_RPP;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void sg_wgrad_kernel(const SgWgradA
   }
 }
 
-template <int BC, int BN, int WM, int WN>
+template <int BC, int BN, int WM, int WN, int BK = 32, int OCC = 2>
 static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int combos = a.ntaps * sg_cdiv(a.Cp, BC) * sg_cdiv(a.Cq, BN);
@@ -184,7 +184,7 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;
   a.mchunk = (int)mchunk;
-  hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN>), dim3((unsigned)(combos * nchunks)),
+  hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC>), dim3((unsigned)(combos * nchunks)),
                      dim3(WM * WN * 64), 0, s, a);
   return sg_launch_status();
 }
@@ -194,10 +194,12 @@ int sg_launch_wgrad(const SgWgradArgs& a, hipStream_t s) {
   if ((long)a.Bn * a.Hp * a.Wp * a.Cp >= (1L << 31) || (long)a.Bn * a.Hq * a.Wq * a.Cq >= (1L << 31))
     return SG_ERR_ARG;
   const bool c_small = a.Cp <= 64, n_small = a.Cq <= 64;
-  if (!c_small && !n_small) return launch_wgrad_cfg<128, 128, 2, 2>(a, s);
-  if (!c_small) return launch_wgrad_cfg<128, 64, 2, 2>(a, s);
-  if (!n_small) return launch_wgrad_cfg<64, 128, 2, 2>(a, s);
-  return launch_wgrad_cfg<64, 64, 2, 2>(a, s);
+  static const int bk_env = getenv("SG_WGRAD_BK") ? atoi(getenv("SG_WGRAD_BK")) : 16;   // tuning knob
+  if (!c_small && !n_small)
+    return bk_env == 16 ? launch_wgrad_cfg<128, 128, 2, 2, 16, 3>(a, s) : launch_wgrad_cfg<128, 128, 2, 2>(a, s);
+  if (!c_small) return bk_env == 16 ? launch_wgrad_cfg<128, 64, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<128, 64, 2, 2>(a, s);
+  if (!n_small) return bk_env == 16 ? launch_wgrad_cfg<64, 128, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<64, 128, 2, 2>(a, s);
+  return bk_env == 16 ? launch_wgrad_cfg<64, 64, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<64, 64, 2, 2>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,100 @@
+"""Data-parallel train_step rehearsed on ONE GPU: two processes share cuda:0 and exchange over gloo
+(RCCL refuses two ranks on one device; the reducer is backend-agnostic).  The 2-rank step on a global
+batch of 4 must reproduce the single-process step on the same batch: the 16 scalars, the SUM-reduced
+gradients and the post-Adam weights -- which exercises input sharding, the fp64 loss-statistics
+all-reduce, SyncBN (forward sums + backward sums) and the flat gradient all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(seed=11, B=4, L_r=2, L_f=3):
+    g = torch.Generator().manual_seed(seed)
+    images = (torch.rand(B, 32, 16 * L_r, 1, generator=g) * 2 - 1).numpy()
+    style = (torch.rand(B, 32, 32, 1, generator=g) * 2 - 1).numpy()
+    labels = torch.randint(0, 52, (B, L_r), generator=g).numpy().astype(np.int32)
+    fake = torch.randint(0, 52, (B, L_f), generator=g).numpy().astype(np.int32)
+    return images, style, labels, fake
+
+
+def _run_step(reducer, dev, balance):
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
+    from scrabble_gan_amd.main import build_models
+    NA._model_counter[0] = 0
+    NA.configure(device=dev, seed=5, reducer=reducer)
+    G, D, R, S, gan = build_models((32, 160, 1), 128, (32, 8192), None, "B3", "B1", 52, None)
+    for m in (G, D, S):                       # non-zero sigma so the attention path matters
+        for k in m.store.names:
+            if k.endswith(".sigma"):
+                m.store.p[k].fill_(0.3)
+    images, style, labels, fake = _problem()
+    opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+    out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], style, images.shape[0], 128,
+                        net_loss.hinge, 1, int(balance), None, 10, "", fake_labels=fake, verbose=False)
+    grads = {n: m.store.grad.detach().cpu().clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}
+    weights = {n: m.store.flat.detach().cpu().clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}
+    return [float(v) for v in out], grads, weights
+
+
+def _worker(rank, world, port, balance, ref_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from scrabble_gan_amd.dist import DistReducer
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        out, grads, weights = _run_step(DistReducer(), dev, balance)
+        if rank == 0:          # compare here: only small numbers travel back through the queue
+            ref = torch.load(ref_path, weights_only=True)
+            stats = {}
+            for n in ("D", "R", "S", "G"):
+                stats[n] = ((grads[n] - ref["grads"][n]).abs().max().item(), ref["grads"][n].abs().max().item(),
+                            (weights[n] - ref["weights"][n]).abs().max().item())
+            q.put(("ok", out, stats))
+        dist.barrier()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("FAIL", "%r\n%s" % (e, traceback.format_exc()), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("balance", [False, True])
+def test_two_rank_step_equals_single_process(dev, balance, tmp_path):
+    from scrabble_gan_amd.nn import Reducer
+    ref_out, ref_grads, ref_w = _run_step(Reducer(), dev, balance)
+    ref_path = str(tmp_path / "dp_ref.pt")
+    torch.save({"grads": ref_grads, "weights": ref_w}, ref_path)
+    del ref_grads, ref_w
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, balance, ref_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, out, stats = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", out
+    for i, (a, b) in enumerate(zip(out, ref_out)):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), "scalar %d: dp %r vs single %r" % (i, a, b)
+    for n in ("D", "R", "S", "G"):
+        err, scale, werr = stats[n]
+        # fp32 summation order differs (per-rank partial sums, atomics): 1e-3 of the largest gradient
+        assert err <= 1e-3 * scale, "%s gradients: max err %.3e vs scale %.3e" % (n, err, scale)
+        assert werr <= 4.1e-4, n

@@ -59,7 +59,13 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   const int n0 = (wg % n_tiles) * BN;
 
   const int kchunks = (p.Ca + BK - 1) / BK;
-  const int KT = p.ntaps * kchunks;
+  const int KT_all = p.ntaps * kchunks;
+  // split-K (gridDim.y > 1): this workgroup reduces k-tiles [kt_begin, kt_begin + KT) and adds its partial
+  // tile to the (pre-zeroed or accumulated-into) output with float atomics; all fused epilogue terms
+  // used with it (bias, 0/1 mask, accumulate) are linear in the partial sums
+  const int nsplit = gridDim.y, split = blockIdx.y;
+  const int kt_begin = (int)(((long)KT_all * split) / nsplit);
+  const int KT = (int)(((long)KT_all * (split + 1)) / nsplit) - kt_begin;
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
 
   // ---- per-thread operand rows: everything that does not depend on the k-tile is hoisted, so the
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
 
   float4 a_reg[A_P];
   float4 b_reg[B_P];
-  int lt = 0, lc0 = 0;   // (tap, channel offset) of the next k-tile to fetch
+  int lt = kt_begin / kchunks, lc0 = (kt_begin - (kt_begin / kchunks) * kchunks) * BK;   // (tap, channel offset) of the next k-tile to fetch
 
   auto load_a = [&]() {
     const int tap_off = (p.taps[lt].dy * p.Wa + p.taps[lt].dx) * p.Ca + lc0;
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
     const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
     if (n >= p.N) continue;
     float bsum = 0.f;
-    if (p.bias) bsum += p.bias[n];
-    if (p.bias2) bsum += p.bias2[n];
+    if (p.bias && split == 0) bsum += p.bias[n];
+    if (p.bias2 && split == 0) bsum += p.bias2[n];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -251,6 +257,10 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
         }
         float v = acc[i][j][r] + bsum;
         if (p.mask && p.mask[idx] <= 0.f) v = 0.f;
+        if (nsplit > 1) {
+          atomicAdd(p.out + idx, v);
+          continue;
+        }
         if (accum) v += p.out[idx];
         if (relu_out) v = fmaxf(v, 0.f);
         p.out[idx] = v;
@@ -266,10 +276,27 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int grid = sg_cdiv(M, BM) * sg_cdiv(a.N, BN);
   if (grid <= 0) return SG_OK;
+  // split-K when the tile grid cannot fill the chip (small per-GPU batches under data parallelism):
+  // aim at >= ~3 workgroups per CU, keep >= 16 k-tiles per split; not with a non-linear epilogue
+  static const int split_env = getenv("SG_IGEMM_SPLITK") ? atoi(getenv("SG_IGEMM_SPLITK")) : 0;
+  const int KT_all = a.ntaps * sg_cdiv(a.Ca, BK);
+  int nsplit = 1;
+  if (!(a.flags & SG_RELU_OUT) && grid < 768 && KT_all >= 32) {
+    nsplit = (1024 + grid - 1) / grid;
+    if (nsplit > KT_all / 16) nsplit = KT_all / 16;
+    if (nsplit > 16) nsplit = 16;
+    if (nsplit < 1) nsplit = 1;
+  }
+  if (split_env > 0 && !(a.flags & SG_RELU_OUT)) nsplit = split_env < KT_all ? split_env : 1;
+  if (nsplit > 1 && !(a.flags & SG_ACCUM)) {
+    if (!(a.flags & SG_IDENT_OUT)) nsplit = 1;   // strided output placement (transposed conv): keep the single pass
+    else if (hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)M * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  }
+  const dim3 g3(grid, nsplit);
   if (b_nk)
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   else
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   return sg_launch_status();
 }
 

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* theta, const floa
   __shared__ __attribute__((aligned(16))) float ks[AT_KT * AT_DK];
   __shared__ __attribute__((aligned(16))) float vs[AT_KT * AT_DV];
   const int b = blockIdx.y;
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = qi < Nq;
   float q[AT_DK];
 #pragma unroll
@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* theta, const floa
   for (int k0 = 0; k0 < Nk; k0 += AT_KT) {
     const int kn = min(AT_KT, Nk - k0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += 256)
+    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += blockDim.x)
       reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
           ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += 256)
+    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += blockDim.x)
       reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
           ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* theta, const f
   __shared__ __attribute__((aligned(16))) float ks[AT_KT * AT_DK];
   __shared__ __attribute__((aligned(16))) float vs[AT_KT * AT_DV];
   const int b = blockIdx.y;
-  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = qi < Nq;
   const size_t row = (size_t)b * Nq + (live ? qi : 0);
   float q[AT_DK], dq[AT_DK], dO[AT_DV];
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* theta, const f
   for (int k0 = 0; k0 < Nk; k0 += AT_KT) {
     const int kn = min(AT_KT, Nk - k0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += 256)
+    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += blockDim.x)
       reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
           ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += 256)
+    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += blockDim.x)
       reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
           ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
                                                       const float* dout, const float* delta, float* dphi, float* dg, int Nq, int Nk) {
   __shared__ __attribute__((aligned(16))) float qs[AT_KT * AT_QREC];
   const int b = blockIdx.y;
-  const int kj = blockIdx.x * 256 + threadIdx.x;
+  const int kj = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = kj < Nk;
   const size_t krow = (size_t)b * Nk + (live ? kj : 0);
   float k[AT_DK], v[AT_DV], dk[AT_DK], dv[AT_DV];
@@ -150,17 +150,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
   for (int q0 = 0; q0 < Nq; q0 += AT_KT) {
     const int qn = min(AT_KT, Nq - q0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * 2; e += 256) {       // theta: 2 float4 per query
+    for (int e = threadIdx.x; e < AT_KT * 2; e += blockDim.x) {       // theta: 2 float4 per query
       const int i = e >> 1, h = e & 1;
       reinterpret_cast<float4*>(qs + i * AT_QREC)[h] =
           i < qn ? reinterpret_cast<const float4*>(theta + ((size_t)b * Nq + q0 + i) * AT_DK)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int e = threadIdx.x; e < AT_KT * 8; e += 256) {       // dO: 8 float4 per query
+    for (int e = threadIdx.x; e < AT_KT * 8; e += blockDim.x) {       // dO: 8 float4 per query
       const int i = e >> 3, h = e & 7;
       reinterpret_cast<float4*>(qs + i * AT_QREC + 8)[h] =
           i < qn ? reinterpret_cast<const float4*>(dout + ((size_t)b * Nq + q0 + i) * AT_DV)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = threadIdx.x; i < AT_KT; i += 256) {
+    for (int i = threadIdx.x; i < AT_KT; i += blockDim.x) {
       qs[i * AT_QREC + 40] = i < qn ? lse[(size_t)b * Nq + q0 + i] : INFINITY;   // p = exp(s - inf) = 0 for padding
       qs[i * AT_QREC + 41] = i < qn ? delta[(size_t)b * Nq + q0 + i] : 0.f;
     }
@@ -193,11 +193,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
   }
 }
 
+// one lane per row; 64-lane workgroups when 256-lane ones would leave most of the 256 CUs idle
+static inline int at_threads(int rows, int B) { return (long)sg_cdiv(rows, 256) * B >= 1024 ? 256 : 64; }
+
 // theta [B,Nq,8], phi [B,Nk,8], g [B,Nk,32] -> out [B,Nq,32], lse [B,Nq]
 extern "C" int sg_attention_fwd(const float* theta, const float* phi, const float* g, float* out, float* lse, int B, int Nq,
                                 int Nk, int dk, int dv, void* stream) {
   if (!theta || !phi || !g || !out || !lse || dk != AT_DK || dv != AT_DV || Nk < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_fwd, dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
+  const int tq = at_threads(Nq, B);
+  hipLaunchKernelGGL(k_attn_fwd, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
   return sg_launch_status();
 }
 
@@ -207,9 +211,10 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
                                 int dk, int dv, void* stream) {
   if (!theta || !phi || !g || !out || !lse || !dout || !dtheta || !dphi || !dg || !delta || dk != AT_DK || dv != AT_DV || Nk < 1)
     return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
+  const int tq = at_threads(Nq, B), tk = at_threads(Nk, B);
+  hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
                      dtheta, delta, Nq, Nk);
-  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(sg_cdiv(Nk, 256), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, lse, dout,
+  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(sg_cdiv(Nk, tk), B), dim3(tk), 0, (hipStream_t)stream, theta, phi, g, lse, dout,
                      delta, dphi, dg, Nq, Nk);
   return sg_launch_status();
 }

@@ -269,6 +269,9 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   }
 }
 
+static int g_split_override = -1;   // tuning/debug: -1 = heuristic, 1 = never split, n > 1 = force n splits
+extern "C" void sg_debug_set_splitk(int n) { g_split_override = n; }
+
 template <int BM, int BN, int WM, int WN, int BK = SG_BK, int OCC = 2>
 static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   SgIgemmArgs a = a_in;
@@ -278,7 +281,8 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   if (grid <= 0) return SG_OK;
   // split-K when the tile grid cannot fill the chip (small per-GPU batches under data parallelism):
   // aim at >= ~3 workgroups per CU, keep >= 16 k-tiles per split; not with a non-linear epilogue
-  static const int split_env = getenv("SG_IGEMM_SPLITK") ? atoi(getenv("SG_IGEMM_SPLITK")) : 0;
+  static const int split_env0 = getenv("SG_IGEMM_SPLITK") ? atoi(getenv("SG_IGEMM_SPLITK")) : 0;
+  const int split_env = g_split_override >= 0 ? g_split_override : split_env0;
   const int KT_all = a.ntaps * sg_cdiv(a.Ca, BK);
   int nsplit = 1;
   if (!(a.flags & SG_RELU_OUT) && grid < 768 && KT_all >= 32) {

@@ -265,7 +265,8 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   if (M <= 0) return SG_OK;
   if ((a.C & 3) || 256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
-  int ppb = 2048;
+  int ppb = (int)(M / 1024);                      // ~1024 workgroups; 128..2048 pixels each
+  ppb = ppb < 128 ? 128 : (ppb > 2048 ? 2048 : ppb);
   const int grid = sg_cdiv(M, ppb);
   hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), 0, s, a, ppb);
   return sg_launch_status();

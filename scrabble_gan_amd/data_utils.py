@@ -171,13 +171,18 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     for m in (D, R, S):
         m.store.zero_grad()
     discriminator.trainable = True
+    # Each network's flat gradient buffer starts its SUM all-reduce (data parallel; the targets are [B,1]
+    # vectors) as soon as its sweeps are queued, so the D/R/S exchanges overlap G's backward.
     D.backward(ctx_dr, gD_r, want_dx=False, want_dw=True)
     D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
+    pending = [red.all_reduce_sum_async(D.store.grad)]
     recognizer.trainable = True
     R.backward(ctx_rr, torch.ones_like(r_r), want_dx=False, want_dw=True)          # target r_real_logits: CTC on real only
+    pending.append(red.all_reduce_sum_async(R.store.grad))
     style_promoter.trainable = True
     S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
     S.backward(ctx_sf, gS_f, want_dx=False, want_dw=True)
+    pending.append(red.all_reduce_sum_async(S.store.grad))
     g_step = (batch_idx + 1) % disc_iters == 0
     if g_step:
         recognizer.trainable = False
@@ -189,9 +194,11 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         ops.add(dx, R.backward(ctx_rf, gG_r, want_dx=True, want_dw=False), out=dx)
         G.backward(ctx_g, dx)
 
-    # ---- gradient exchange (data parallel: SUM, the targets are [B,1] vectors) + updates ----
-    for m in (D, R, S) + ((G,) if g_step else ()):
-        red.all_reduce_sum(m.store.grad)
+    # ---- finish the gradient exchange, then the four updates ----
+    if g_step:
+        pending.append(red.all_reduce_sum_async(G.store.grad))
+    for h in pending:
+        red.wait(h)
     discriminator_optimizer.apply_flat(D.store)
     recognizer_optimizer.apply_flat(R.store)
     stylepromoter_optimizer.apply_flat(S.store)

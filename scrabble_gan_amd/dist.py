@@ -26,6 +26,17 @@ class DistReducer(Reducer):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """RCCL runs the reduction on its own stream (ordered after the kernels already queued on the
+        current stream), so D/R/S gradient exchange overlaps the generator's backward sweep."""
+        if self.world_size == 1:
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self, handle) -> None:
+        if handle is not None:
+            handle.wait()        # makes the current stream wait for the collective; no host block on nccl
+
     def shard(self, t: torch.Tensor) -> torch.Tensor:
         """This rank's contiguous slice [r*B/P, (r+1)*B/P) of a per-step batch tensor."""
         B = t.shape[0]

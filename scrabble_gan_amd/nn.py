@@ -115,6 +115,13 @@ class Reducer:
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         return t
 
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        """Start a SUM all-reduce of `t` that may overlap later kernels; returns a handle for wait()."""
+        return None
+
+    def wait(self, handle) -> None:
+        return None
+
 
 LOCAL = Reducer()
 

@@ -130,6 +130,19 @@ int sg_loss_grads(const float* d_r, const float* d_f, const float* s_my, const f
 int sg_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, int B, int mode,
                   float* out7, void* stream);
 
+/* ---- make_my_recognizer extras (net_architecture.py:82-179): LeakyReLU(0.01) :104, Dropout masks :112-153,
+ *      Bidirectional(LSTM(256, dropout=0.5)) :146-150 (Keras gate order i,f,c~,o; sigmoid/tanh) ------------- */
+int sg_leaky_relu_fwd(const float* x, float* y, long n, float alpha, void* stream);
+int sg_leaky_relu_bwd(const float* dy, const float* x, float* dx, long n, float alpha, void* stream);
+/* out[r,c] = x[r,c] * mask[r / rows_per_mask, c]  (rows_per_mask = T: one input-dropout mask per sample, all timesteps) */
+int sg_mul_mask(const float* x, const float* mask, float* out, long rows, int cols, int rows_per_mask, void* stream);
+/* z [B,4H] (row stride ldz): pre-activations in, gate activations out; c = f c_prev + i c~; h = o tanh(c) */
+int sg_lstm_cell_fwd(float* z, int ldz, const float* c_prev, float* c_out, float* h_out, int ldh, float* h_copy, int ldc,
+                     int B, int H, void* stream);
+/* gates [B,4H]: activations in, d(pre-activations) out; dh = dh_a (stride lda) + dh_b; dc_prev out */
+int sg_lstm_cell_bwd(float* gates, int ldz, const float* c_prev, const float* c_t, const float* dh_a, int lda, const float* dh_b,
+                     const float* dc_next, float* dc_prev, int B, int H, void* stream);
+
 /* ---- optimizers (main.py:27-33; Keras Adam / RMSprop) and spectral_norm (arch_ops.py:98-126) */
 int sg_adam_update(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta_1, float beta_2, float eps, void* stream);
 int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream);

@@ -259,6 +259,90 @@ def recognizer(x: Tensor, labels: Tensor, input_length: int, label_length: int,
     return ctc_batch_cost(labels, recognizer_probs(x, p, bn_training), input_length, label_length)
 
 
+MYREC_FILTERS = [16, 32, 48, 64, 80, 128, 144]            # net_architecture.py:102-136
+MYREC_POOLS = [(2, 2), (2, 2), (2, 1), (2, 1), (2, 1), None, None]
+
+
+def lstm_direction(x: Tensor, W: Tensor, U: Tensor, b: Tensor, reverse: bool) -> Tensor:
+    """One direction of layers.LSTM(units, return_sequences=True) (net_architecture.py:146): Keras gate order
+    i, f, c~, o; sigmoid recurrent activation, tanh activation; zero initial state.  x [B,T,I] -> [B,T,H]."""
+    B, T, _ = x.shape
+    H = U.shape[0]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        z = x[:, t] @ W + h @ U + b
+        i, f, g, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        outs[t] = h
+    return torch.stack(outs, dim=1)
+
+
+def bilstm(x: Tensor, p: Dict[str, Tensor], pre: str, masks=None) -> Tensor:
+    """Bidirectional(LSTM(256, return_sequences=True, dropout=0.5)), merge_mode concat.  `masks` = (fw, bw) input-dropout
+    masks [B,I] already scaled by 1/(1-rate), one per direction, shared by all timesteps (Keras implementation 2)."""
+    outs = []
+    for k, d in enumerate(("fw", "bw")):
+        xm = x if masks is None else x * masks[k].unsqueeze(1)
+        outs.append(lstm_direction(xm, p[pre + "." + d + ".W"], p[pre + "." + d + ".U"], p[pre + "." + d + ".b"], reverse=(d == "bw")))
+    return torch.cat(outs, dim=-1)
+
+
+def my_recognizer_probs(x: Tensor, p: Dict[str, Tensor], bn_training: bool = False, masks: Optional[dict] = None) -> Tensor:
+    """make_my_recognizer conv + BiLSTM stack + per-frame softmax (net_architecture.py:102-154).  `masks` holds the
+    dropout masks of a training call (already scaled): 'drop3'..'drop7' (activation-shaped, rate 0.2, :112-135),
+    'lstm{l}' = (fw, bw) [B,I] (rate 0.5), 'drop_out' [B,T,512] (:153); None = inference (no dropout)."""
+    net = x
+    for i, (co, pool) in enumerate(zip(MYREC_FILTERS, MYREC_POOLS)):
+        k = i + 1
+        if masks is not None and k >= 3:
+            net = net * masks["drop%d" % k]
+        net = conv2d(net, p["conv%d.w" % k], p["conv%d.b" % k])
+        if bn_training:
+            x_hat, _, _ = batch_norm_train(net)
+        else:
+            x_hat = (net - p["bn%d.mm" % k]) * torch.rsqrt(p["bn%d.mv" % k] + BN_EPS)
+        net = F.leaky_relu(x_hat * p["bn%d.gamma" % k] + p["bn%d.beta" % k], 0.01)
+        if pool is not None:
+            net = max_pool(net, *pool)
+    net = net.squeeze(1)                                                    # :143
+    for l in range(5):
+        net = bilstm(net, p, "lstm%d" % (l + 1), None if masks is None else masks["lstm%d" % (l + 1)])
+    if masks is not None:
+        net = net * masks["drop_out"]
+    return torch.softmax(net @ p["dense.w"] + p["dense.b"], dim=-1)          # :154
+
+
+def my_recognizer(x, labels, input_length, label_length, p, bn_training=False, masks=None) -> Tensor:
+    return ctc_batch_cost(labels, my_recognizer_probs(x, p, bn_training, masks), input_length, label_length)
+
+
+def init_my_recognizer(gen: torch.Generator, dtype=torch.float64, classes=53, H=256) -> Dict[str, Tensor]:
+    p: Dict[str, Tensor] = {}
+    cin = 1
+    for i, co in enumerate(MYREC_FILTERS):
+        k = i + 1
+        p["conv%d.w" % k] = glorot_uniform((3, 3, cin, co), gen, dtype)
+        p["conv%d.b" % k] = torch.zeros(co, dtype=dtype)
+        p["bn%d.gamma" % k], p["bn%d.beta" % k] = torch.ones(co, dtype=dtype), torch.zeros(co, dtype=dtype)
+        p["bn%d.mm" % k], p["bn%d.mv" % k] = torch.zeros(co, dtype=dtype), torch.ones(co, dtype=dtype)
+        cin = co
+    for l in range(5):
+        for d in ("fw", "bw"):
+            pre = "lstm%d.%s" % (l + 1, d)
+            p[pre + ".W"] = glorot_uniform((cin, 4 * H), gen, dtype)
+            p[pre + ".U"] = orthogonal((H, 4 * H), gen, dtype)
+            b = torch.zeros(4 * H, dtype=dtype)
+            b[H:2 * H] = 1.0                                                 # unit_forget_bias
+            p[pre + ".b"] = b
+        cin = 2 * H
+    p["dense.w"] = glorot_uniform((2 * H, classes), gen, dtype)
+    p["dense.b"] = torch.zeros(classes, dtype=dtype)
+    return p
+
+
 # --------------------------------------------------------------------------------------------
 # losses (net_loss.py) and gradient balancing (data_utils.py:476-490)
 # --------------------------------------------------------------------------------------------

@@ -15,10 +15,12 @@
 __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* x, float* partial, long M, int C, int rows_per_block) {
   __shared__ float4 r1[256], r2[256];
   const int cqn = C >> 2;
-  const int cq = threadIdx.x % cqn, rl = threadIdx.x / cqn, lanes = 256 / cqn;
+  const int cq = threadIdx.x % cqn, rl = threadIdx.x / cqn;
+  int lanes = 1;                                   // row lanes: largest power of two with lanes*cqn <= 256
+  while (lanes * 2 * cqn <= 256) lanes *= 2;
   const long m0 = (long)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-  for (long m = m0 + rl; m < m1; m += lanes) {
+  for (long m = m0 + rl; m < m1 && rl < lanes; m += lanes) {
     const float4 v = CF4(x + m * C + 4 * cq);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
@@ -87,13 +89,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* dy, const fl
                                                        float eps, int relu, int rows_per_block) {
   __shared__ float4 r1[256], r2[256];
   const int cqn = C >> 2;
-  const int cq = threadIdx.x % cqn, rl = threadIdx.x / cqn, lanes = 256 / cqn;
+  const int cq = threadIdx.x % cqn, rl = threadIdx.x / cqn;
+  int lanes = 1;
+  while (lanes * 2 * cqn <= 256) lanes *= 2;
   const int b = blockIdx.y;
   const int m0 = blockIdx.x * rows_per_block, m1 = min(HW, m0 + rows_per_block);
   const float4 mu = CF4(mean + 4 * cq), va = CF4(var + 4 * cq);
   const float4 rs = make_float4(rsqrtf(va.x + eps), rsqrtf(va.y + eps), rsqrtf(va.z + eps), rsqrtf(va.w + eps));
   float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
-  for (int m = m0 + rl; m < m1; m += lanes) {
+  for (int m = m0 + rl; m < m1 && rl < lanes; m += lanes) {
     const size_t off = ((size_t)b * HW + m) * C + 4 * cq;
     float4 g = CF4(dy + off);
     if (relu) {
@@ -185,7 +189,7 @@ __global__ void k_bn_update_moving(float* mm, float* mv, const float* mean, cons
   mv[c] = momentum * mv[c] + (1.f - momentum) * var[c] * corr;
 }
 
-static inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256 && (256 % (C >> 2)) == 0; }
+static inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256; }
 
 extern "C" long sg_bn_stats_workspace_floats(long M, int C) { return (long)sg_cdiv(M, 2048) * 2 * C; }
 

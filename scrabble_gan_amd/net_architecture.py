@@ -487,11 +487,129 @@ def make_recognizer(input_dim, sequence_length, output_classes, vis_model=True):
     return m
 
 
+_MYREC_FILTERS = [16, 32, 48, 64, 80, 128, 144]
+_MYREC_POOLS = [(2, 2), (2, 2), (2, 1), (2, 1), (2, 1), None, None]
+
+
+class MyRecognizerModel(RecognizerModel):
+    """make_my_recognizer (net_architecture.py:82-179): 7 x [Conv3x3 -> BatchNorm -> LeakyReLU(0.01)] with five
+    max-pools and Dropout(0.2) before convs 3-7, then 5 x Bidirectional(LSTM(256, dropout=0.5)), Dropout(0.5),
+    Dense(softmax) and the same CTC head.  T = W/4 frames; CTC reads the first 4L-1 of them.  Dropout masks are
+    drawn on the device when training (or passed explicitly for parity tests)."""
+
+    LSTM_H = 256
+
+    def __init__(self, input_dim, sequence_length, output_classes):
+        h, w, c = input_dim
+        specs, cin = [], c
+        for i, co in enumerate(_MYREC_FILTERS):
+            k = i + 1
+            specs += [("conv%d.w" % k, (3, 3, cin, co), nn.glorot_uniform, True), ("conv%d.b" % k, (co,), nn.zeros, True),
+                      ("bn%d.gamma" % k, (co,), nn.ones, True), ("bn%d.beta" % k, (co,), nn.zeros, True),
+                      ("bn%d.mm" % k, (co,), nn.zeros, False), ("bn%d.mv" % k, (co,), nn.ones, False)]
+            cin = co
+        for l in range(5):
+            specs += nn.bilstm_specs("lstm%d" % (l + 1), cin, self.LSTM_H)
+            cin = 2 * self.LSTM_H
+        specs += [("dense.w", (cin, output_classes), nn.glorot_uniform, True), ("dense.b", (output_classes,), nn.zeros, True)]
+        _Model.__init__(self, "my_recognizer", specs, _gen_for("my_recognizer"))
+        self.classes = output_classes
+        self.mask_gen = torch.Generator(device=self.device)
+        self.mask_gen.manual_seed(_DEFAULTS["seed"] * 1000 + 991)
+
+    def _drop(self, shape, rate):
+        keep = torch.rand(shape, device=self.device, generator=self.mask_gen) >= rate
+        return keep.float() / (1.0 - rate)
+
+    def draw_masks(self, B, W):
+        """Dropout masks of one training call (values 0 or 1/(1-rate))."""
+        m = {}
+        hh, ww, cin = 32, W, 1
+        for i, (co, pool) in enumerate(zip(_MYREC_FILTERS, _MYREC_POOLS)):
+            if i + 1 >= 3:
+                m["drop%d" % (i + 1)] = self._drop((B, hh, ww, cin), 0.2)
+            if pool is not None:
+                hh, ww = hh // pool[0], ww // pool[1]
+            cin = co
+        for l in range(5):
+            m["lstm%d" % (l + 1)] = (self._drop((B, cin), 0.5), self._drop((B, cin), 0.5))
+            cin = 2 * self.LSTM_H
+        m["drop_out"] = self._drop((B, ww, cin), 0.5)
+        return m
+
+    def forward(self, x, labels, input_length, label_length, training=True, need_grad=True, masks=None):
+        p, S = self.store.p, self.store
+        x = _as_nhwc1(x, self.device)
+        labels = _as_labels(labels, self.device)
+        bn_training = bool(training and self.trainable)        # TF2: training AND layer.trainable
+        if training and masks is None:
+            masks = self.draw_masks(x.shape[0], x.shape[2])      # Keras Dropout follows `training` only
+        acts, net = [], x
+        for i, (co, pool) in enumerate(zip(_MYREC_FILTERS, _MYREC_POOLS)):
+            k = i + 1
+            rec = {}
+            if masks is not None and k >= 3:
+                net = ops.mul_mask(net, masks["drop%d" % k])
+            rec["in"] = net
+            conv = ops.conv2d_fwd(net, p["conv%d.w" % k], p["conv%d.b" % k])
+            bn_out, rec["bn"] = self._bn_fwd(conv, "bn%d" % k, bn_training)
+            rec["bn_out"] = bn_out
+            net = ops.leaky_relu_fwd(bn_out, 0.01)
+            if pool is not None:
+                net, rec["idx"] = ops.maxpool_fwd(net, *pool)
+            acts.append(rec)
+        B, one, T, C = net.shape
+        assert one == 1, net.shape
+        seq = net.view(B, T, C)
+        lstm_ctx = []
+        for l in range(5):
+            seq, c = nn.bilstm_fwd(seq, S, "lstm%d" % (l + 1), None if masks is None else masks["lstm%d" % (l + 1)])
+            lstm_ctx.append(c)
+        if masks is not None:
+            seq = ops.mul_mask(seq, masks["drop_out"])
+        feat = seq.reshape(B * T, seq.shape[2])
+        logits = ops.dense_fwd(feat, p["dense.w"], p["dense.b"]).view(B, T, self.classes)
+        loss, dlogits = ops.softmax_ctc(logits, labels, int(input_length), int(label_length), need_grad)
+        return loss, (acts, lstm_ctx, feat, dlogits, masks, (B, T))
+
+    def backward(self, ctx, upstream, want_dx: bool, want_dw: bool):
+        p, g, S = self.store.p, self.store.g, self.store
+        acts, lstm_ctx, feat, dlogits_unit, masks, (B, T) = ctx
+        dl = ops.rowscale(dlogits_unit, upstream.reshape(-1).contiguous()).view(B * T, self.classes)
+        if want_dw:
+            ops.dense_bwd_weight(feat, dl, g["dense.w"])
+            ops.bias_grad(dl, g["dense.b"])
+        d = ops.dense_bwd_input(dl, p["dense.w"]).view(B, T, feat.shape[1])
+        if masks is not None:
+            d = ops.mul_mask(d, masks["drop_out"])
+        for l in reversed(range(5)):
+            d = nn.bilstm_bwd(lstm_ctx[l], d, S, "lstm%d" % (l + 1), want_dw)
+        d = d.reshape(B, 1, T, d.shape[2])
+        for i in reversed(range(len(_MYREC_FILTERS))):
+            k = i + 1
+            rec, pool = acts[i], _MYREC_POOLS[i]
+            if pool is not None:
+                d = ops.maxpool_bwd(d, rec["idx"], *pool)
+            d = ops.leaky_relu_bwd(d, rec["bn_out"], 0.01)
+            d = self._bn_bwd(rec["bn"], d, "bn%d" % k, want_dw)
+            if want_dw:
+                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % k])
+                ops.bias_grad(d, g["conv%d.b" % k])
+            if i == 0 and not want_dx:
+                return None
+            xin = rec["in"]
+            d = ops.conv2d_bwd_data(d, p["conv%d.w" % k], (xin.shape[1], xin.shape[2]))
+            if masks is not None and k >= 3:
+                d = ops.mul_mask(d, masks["drop%d" % k])
+        return d
+
+
 def make_my_recognizer(input_dim, sequence_length, output_classes, vis_model=True):
-    """CRNN with 5 BiLSTM layers (net_architecture.py:82-179), gin default off (`my_rec=0`).
-    Not built yet: the LSTM recurrences need their own kernels ('not yet built')."""
-    raise NotImplementedError("make_my_recognizer (BiLSTM recognizer) is not built in this round; use make_recognizer "
-                              "(scrabble_gan.gin: shared_specs.my_rec=0)")
+    """CRNN with 5 BiLSTM layers (net_architecture.py:82-179); selected by `shared_specs.my_rec = 1`."""
+    m = MyRecognizerModel(input_dim, sequence_length, output_classes)
+    if vis_model:
+        m.summary()
+    return m
 
 
 def make_gan(g_model, d_model, r_model, w_model, vis_model=True):

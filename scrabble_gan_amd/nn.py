@@ -326,3 +326,101 @@ def block_up_bwd(ctx, dout, z, dz, zi: int, S: ParamStore, pre: str, reducer: Re
     ops.conv2d_transpose_bwd_weight(x, dout, g[pre + ".short.w"], stride=stride)
     ops.conv2d_transpose_bwd_data(dout, p[pre + ".short.w"], stride=stride, out=dx, accum=True)
     return dx
+
+
+# --------------------------------------------------------------------------------------------
+# Bidirectional(LSTM(H, return_sequences=True, dropout=p)) (net_architecture.py:146-150)
+# --------------------------------------------------------------------------------------------
+def lstm_forget_bias(shape, gen=None):
+    """Keras LSTM bias: zeros with unit_forget_bias=True -> ones on the forget-gate quarter (order i,f,c,o)."""
+    b = torch.zeros(tuple(shape))
+    h = shape[0] // 4
+    b[h:2 * h] = 1.0
+    return b
+
+
+def lstm_recurrent_orthogonal(shape, gen):
+    return orthogonal(shape, gen)
+
+
+def bilstm_specs(pre: str, in_dim: int, H: int):
+    s = []
+    for d in ("fw", "bw"):
+        s += [(pre + "." + d + ".W", (in_dim, 4 * H), glorot_uniform, True), (pre + "." + d + ".U", (H, 4 * H), lstm_recurrent_orthogonal, True),
+              (pre + "." + d + ".b", (4 * H,), lstm_forget_bias, True)]
+    return s
+
+
+def _lstm_dir_fwd(xm, W, U, b, out, col_off, reverse: bool):
+    """xm [B,T,I] (already dropout-masked) -> writes h_t into out[:, t, col_off:col_off+H].  Returns ctx."""
+    B, T, I = xm.shape
+    H = U.shape[0]
+    # x W + b for every timestep at once on the MFMA conv kernel (a 1x1 convolution over [B,T,1,I])
+    z = ops.conv2d_fwd(xm.view(B, T, 1, I), W.view(1, 1, I, 4 * H), b).view(B, T, 4 * H)
+    cs = ops.empty(T, B, H, like=xm)                    # c_t, time-major
+    hprev = torch.zeros(B, T, H, device=xm.device)      # h_{t-1} as seen by step t (zeros at the first step)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    prev_t = None
+    for t in order:
+        if prev_t is not None:                          # z_t += h_{t-1} U   (in place, strided rows)
+            ops.gemm(hprev, U, B, 4 * H, H, T * H, 4 * H, out=z, ldc=T * 4 * H, beta=1.0, A_off=t * H, out_off=t * 4 * H)
+        nxt = t - 1 if reverse else t + 1
+        has_next = 0 <= nxt < T
+        ops.lstm_cell_fwd(z, t * 4 * H, T * 4 * H, None if prev_t is None else cs[prev_t], cs[t], out, t * out.shape[2] + col_off,
+                          T * out.shape[2], hprev if has_next else None, (nxt * H) if has_next else 0, T * H, B, H)
+        prev_t = t
+    return (xm, z, cs, hprev, reverse)
+
+
+def _lstm_dir_bwd(ctx, dout, col_off, W, U, gW, gU, gb):
+    """dout [B,T,2H]; accumulates weight grads; returns d(xm) [B,T,I]."""
+    xm, gates, cs, hprev, reverse = ctx
+    B, T, I = xm.shape
+    H = U.shape[0]
+    order = list(range(T - 1, -1, -1) if reverse else range(T))
+    dh_next, dc_next = None, None
+    for k in range(T - 1, -1, -1):                      # walk the recurrence backwards
+        t = order[k]
+        t_prev = order[k - 1] if k > 0 else None
+        dc_prev = ops.empty(B, H, like=xm)
+        ops.lstm_cell_bwd(gates, t * 4 * H, T * 4 * H, None if t_prev is None else cs[t_prev], cs[t], dout, t * dout.shape[2] + col_off,
+                          T * dout.shape[2], dh_next, dc_next, dc_prev, B, H)
+        if t_prev is not None:                          # dh_{t-1} = dz_t U^T
+            dh_next = ops.gemm(gates, U, B, H, 4 * H, T * 4 * H, 4 * H, transB=True, A_off=t * 4 * H)
+        dc_next = dc_prev
+    dz = gates                                           # now d(pre-activations) for all timesteps [B,T,4H]
+    ops.gemm(hprev.view(B * T, H), dz.view(B * T, 4 * H), H, 4 * H, B * T, H, 4 * H, transA=True, out=gU, beta=1.0)
+    ops.conv2d_bwd_weight(xm.view(B, T, 1, I), dz.view(B, T, 1, 4 * H), gW.view(1, 1, I, 4 * H))
+    ops.bias_grad(dz.view(B * T, 4 * H), gb)
+    return ops.conv2d_bwd_data(dz.view(B, T, 1, 4 * H), W.view(1, 1, I, 4 * H), (T, 1)).view(B, T, I)
+
+
+def bilstm_fwd(x, S: ParamStore, pre: str, masks=None):
+    """x [B,T,I]; masks = (mask_fw, mask_bw) each [B,I] with values 0 or 1/(1-rate) (Keras input dropout: one mask per
+    sample shared by all timesteps), or None when not training."""
+    B, T, I = x.shape
+    H = S.p[pre + ".fw.U"].shape[0]
+    out = ops.empty(B, T, 2 * H, like=x)
+    ctxs = []
+    for di, d in enumerate(("fw", "bw")):
+        xm = x if masks is None else ops.mul_mask(x, masks[di], rows_per_mask=T)
+        ctxs.append(_lstm_dir_fwd(xm, S.p[pre + "." + d + ".W"], S.p[pre + "." + d + ".U"], S.p[pre + "." + d + ".b"], out, di * H,
+                                  reverse=(d == "bw")))
+    return out, (ctxs, masks)
+
+
+def bilstm_bwd(ctx, dout, S: ParamStore, pre: str, want_dw=True):
+    ctxs, masks = ctx
+    H = S.p[pre + ".fw.U"].shape[0]
+    T = dout.shape[1]
+    dx = None
+    for di, d in enumerate(("fw", "bw")):
+        if want_dw:
+            gW, gU, gb = S.g[pre + "." + d + ".W"], S.g[pre + "." + d + ".U"], S.g[pre + "." + d + ".b"]
+        else:
+            gW, gU, gb = (torch.zeros_like(S.p[pre + "." + d + k]) for k in (".W", ".U", ".b"))
+        dxm = _lstm_dir_bwd(ctxs[di], dout, di * H, S.p[pre + "." + d + ".W"], S.p[pre + "." + d + ".U"], gW, gU, gb)
+        if masks is not None:
+            dxm = ops.mul_mask(dxm, masks[di], rows_per_mask=T)
+        dx = dxm if dx is None else ops.add(dx, dxm, out=dx)
+    return dx

@@ -460,3 +460,37 @@ def loss_terms(d_r, d_f, s_my, s_f, s_r, mode: int):
     out = empty(7, B, like=d_r)
     call("sg_loss_terms", _p(d_r), _p(d_f), _p(s_my), _p(s_f), _p(s_r), B, mode, _p(out), _stream())
     return out
+
+
+# ---------------------------------------------------------------- make_my_recognizer extras
+def leaky_relu_fwd(x, alpha=0.01):
+    _chk(x)
+    y = torch.empty_like(x)
+    call("sg_leaky_relu_fwd", _p(x), _p(y), x.numel(), float(alpha), _stream())
+    return y
+
+
+def leaky_relu_bwd(dy, x, alpha=0.01):
+    _chk(dy, x)
+    dx = torch.empty_like(dy)
+    call("sg_leaky_relu_bwd", _p(dy), _p(x), _p(dx), dy.numel(), float(alpha), _stream())
+    return dx
+
+
+def mul_mask(x, mask, rows_per_mask=1):
+    """x [rows, cols] (any leading shape) times mask[rows / rows_per_mask, cols]."""
+    _chk(x, mask)
+    cols = x.shape[-1]
+    out = torch.empty_like(x)
+    call("sg_mul_mask", _p(x), _p(mask), _p(out), x.numel() // cols, cols, int(rows_per_mask), _stream())
+    return out
+
+
+def lstm_cell_fwd(z, z_off, ldz, c_prev, c_out, h_out, h_off, ldh, h_copy, hc_off, ldc, B, H):
+    call("sg_lstm_cell_fwd", z.data_ptr() + 4 * z_off, ldz, _p(c_prev), _p(c_out), h_out.data_ptr() + 4 * h_off, ldh,
+         None if h_copy is None else h_copy.data_ptr() + 4 * hc_off, ldc, B, H, _stream())
+
+
+def lstm_cell_bwd(gates, g_off, ldz, c_prev, c_t, dh_a, a_off, lda, dh_b, dc_next, dc_prev, B, H):
+    call("sg_lstm_cell_bwd", gates.data_ptr() + 4 * g_off, ldz, _p(c_prev), _p(c_t), dh_a.data_ptr() + 4 * a_off, lda, _p(dh_b),
+         _p(dc_next), _p(dc_prev), B, H, _stream())

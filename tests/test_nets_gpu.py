@@ -123,6 +123,49 @@ def test_recognizer(setup, dev):
             close(R.store.g[k], v.grad, 5e-3 if bn_training else 2e-3, "grad %s bn_training=%s" % (k, bn_training), at)
 
 
+def test_my_recognizer(setup, dev):
+    """make_my_recognizer (7 conv/BN/LeakyReLU + 5 BiLSTM + CTC on the first 4L-1 of W/4 frames) with explicit dropout masks."""
+    NA = setup
+    gen = torch.Generator().manual_seed(9)
+    R = NA.make_my_recognizer((32, 160, 1), None, 53, vis_model=False)
+    P = perturb(R, gen)
+    B, L = 3, 2
+    W = 16 * L
+    x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    labels = torch.randint(0, 52, (B, L), generator=gen)
+    up = torch.rand(B, generator=gen, dtype=torch.float64) + 0.5
+
+    def drop(shape, rate):
+        return (torch.rand(shape, generator=gen, dtype=torch.float64) >= rate).double() / (1 - rate)
+    masks = {"drop3": drop((B, 8, W // 4, 32), 0.2), "drop4": drop((B, 4, W // 4, 48), 0.2), "drop5": drop((B, 2, W // 4, 64), 0.2),
+             "drop6": drop((B, 1, W // 4, 80), 0.2), "drop7": drop((B, 1, W // 4, 128), 0.2), "drop_out": drop((B, W // 4, 512), 0.5)}
+    cin = 144
+    for l in range(5):
+        masks["lstm%d" % (l + 1)] = (drop((B, cin), 0.5), drop((B, cin), 0.5))
+        cin = 512
+    gmasks = {k: (tuple(t.float().to(dev) for t in v) if isinstance(v, tuple) else v.float().to(dev)) for k, v in masks.items()}
+    for bn_training in (False, True):
+        Pc = {k: v.clone() for k, v in P.items()}
+        lv = leaves(Pc)
+        xr = x.clone().requires_grad_(True)
+        ref = O.my_recognizer(xr, labels, 4 * L - 1, L, Pc, bn_training=bn_training, masks=masks)
+        (ref[:, 0] * up).sum().backward()
+        R.trainable = bn_training
+        R.store.load({k: v for k, v in P.items() if k.endswith((".mm", ".mv"))})
+        loss, ctx = R.forward(x.float().to(dev), labels.int().to(dev), 4 * L - 1, L, training=True, masks=gmasks)
+        close(loss, ref[:, 0], 2e-4, "ctc cost bn_training=%s" % bn_training)
+        R.store.zero_grad()
+        dx = R.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+        close(dx, xr.grad, 1e-2, "dx")
+        at = net_atol([v.grad for v in lv.values()])
+        for k, v in lv.items():
+            close(R.store.g[k], v.grad, 1e-2 if bn_training else 3e-3, "grad %s bn_training=%s" % (k, bn_training), at)
+    # without masks and with training=False the forward is deterministic inference
+    ref = O.my_recognizer(x, labels, 4 * L - 1, L, P)
+    R.trainable = False
+    close(R([x.float().to(dev), labels.int().to(dev), 4 * L - 1, L], training=False), ref, 2e-4, "inference cost")
+
+
 def test_generator(setup, dev):
     NA = setup
     gen = torch.Generator().manual_seed(7)
@@ -200,7 +243,7 @@ def test_train_step(setup, dev, loss_name, balance):
             got, ref = model.store.p[k].detach().double().cpu(), P1[k].double()
             gr = ref_grads[net][k].double()
             mask = gr.abs() > max(1e-3 * gr.abs().max().item(), 1e-4 * net_max)
-            assert ((got - ref).abs() * mask).max().item() <= 2e-6, "%s weight %s after Adam" % (net, k)
+            assert ((got - ref).abs() * mask).max().item() <= 1e-5, "%s weight %s after Adam" % (net, k)   # 5 % of lr
             assert (got - ref).abs().max().item() <= 4.1e-4, "%s weight %s moved more than 2*lr" % (net, k)
     # trainable flags as left by the reference (:464-466)
     assert not D.trainable and not R.trainable and not S.trainable

@@ -176,6 +176,38 @@ def test_orthogonal_and_glorot_initialisers():
     assert abs(fb.abs().max().item() - math.sqrt(6.0 / (32 * 52 + 8192 * 52))) < 1e-4     # 3.746e-3 (Appendix A-6)
 
 
+def test_lstm_matches_torch_nn_lstm():
+    """Independent pin of the Keras-order LSTM restatement: torch.nn.LSTM uses the same gate order (i,f,g,o) with
+    weights stored transposed and two bias vectors."""
+    gen = g(24)
+    B, T, I, H = 3, 5, 7, 4
+    x = torch.randn(B, T, I, generator=gen, dtype=D)
+    W, U, b = (torch.randn(I, 4 * H, generator=gen, dtype=D), torch.randn(H, 4 * H, generator=gen, dtype=D),
+               torch.randn(4 * H, generator=gen, dtype=D))
+    ref = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for sfx in ("", "_reverse"):
+            getattr(ref, "weight_ih_l0" + sfx).copy_(W.t())
+            getattr(ref, "weight_hh_l0" + sfx).copy_(U.t())
+            getattr(ref, "bias_ih_l0" + sfx).copy_(b)
+            getattr(ref, "bias_hh_l0" + sfx).zero_()
+        out, _ = ref(x)
+    p = {"l.fw.W": W, "l.fw.U": U, "l.fw.b": b, "l.bw.W": W, "l.bw.U": U, "l.bw.b": b}
+    assert torch.allclose(O.bilstm(x, p, "l"), out, atol=1e-12)
+    # input dropout: one mask per sample shared by all timesteps == masking the input sequence
+    m = (torch.rand(B, I, generator=gen, dtype=D) > 0.5).double() * 2
+    assert torch.allclose(O.bilstm(x, p, "l", (m, m)), ref(x * m.unsqueeze(1))[0], atol=1e-12)
+
+
+def test_my_recognizer_shapes_and_frame_count():
+    P = O.init_my_recognizer(g(25))
+    x = torch.rand(2, 32, 64, 1, generator=g(26), dtype=D)
+    probs = O.my_recognizer_probs(x, P)
+    assert probs.shape == (2, 16, 53) and torch.allclose(probs.sum(-1), torch.ones(2, 16, dtype=D))     # T = W/4
+    b = P["lstm1.fw.b"]
+    assert b[:256].abs().sum() == 0 and (b[256:512] == 1).all() and b[512:].abs().sum() == 0           # unit_forget_bias
+
+
 def test_parameter_counts():
     """G 53.7 M, D 37.3 M, R 5.6 M trainable parameters."""
     n = lambda P: sum(v.numel() for k, v in P.items() if O.is_trainable(k))

@@ -88,6 +88,40 @@ def test_bookkeeping_is_bit_exact():
     assert idx == idx2 and fl.dtype == np.int32 and (fl == fl2).all() and fl.shape == (5, idx + 1)
 
 
+def test_bucket_folder_reader(tmp_path):
+    """load_prepare_data on the reference's on-disk layout <read_dir>/<L>/<name>.png + .txt (pixels and labels bit-exact)."""
+    from PIL import Image
+    from scrabble_gan_amd import data_io
+    cv = 'abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
+    rng = np.random.default_rng(0)
+    truth = {}
+    for L, words in ((1, ["a", "Z"]), (2, ["to", "Hi", "ab"])):
+        d = tmp_path / str(L)
+        d.mkdir()
+        for i, wd in enumerate(words):
+            px = rng.integers(0, 256, (32, 16 * L), dtype=np.uint8)
+            Image.fromarray(px, mode="L").save(d / ("w%d.png" % i))
+            (d / ("w%d.txt" % i)).write_text(wd)
+            truth[tuple(data_io.encode_word(wd, cv))] = px
+    gen = data_io.load_prepare_data((32, 160, 1), 4, str(tmp_path) + "/", cv, 2)
+    random.seed(1)
+    np.random.seed(1)
+    for _ in range(5):
+        imgs, labels = next(gen)
+        L = labels.shape[1]
+        assert imgs.shape == (4, 32, 16 * L, 1) and imgs.dtype == np.float32 and labels.dtype == np.int32
+        for im, lab in zip(imgs, labels):
+            assert np.array_equal(im[:, :, 0], (truth[tuple(lab)].astype('float32') - 127.5) / 127.5)
+    # style images: height-normalised to 32, cropped / white-padded to 160, in [-1,1]
+    sdir = tmp_path / "style"
+    sdir.mkdir()
+    for i, (hh, ww) in enumerate([(64, 200), (32, 400), (40, 90)] * 7):
+        Image.fromarray(rng.integers(0, 256, (hh, ww), dtype=np.uint8), mode="L").save(sdir / ("s%d.png" % i))
+    tr, va = data_io.load_style_input((32, 160, 1), 4, 10, str(sdir))
+    assert len(tr) == 19 and len(va) == 2 and all(t.shape == (32, 160) for t in tr)
+    assert all(-1.0 - 1e-6 <= t.min() and t.max() <= 1.0 + 1e-6 for t in tr)
+
+
 def test_reference_api_surface():
     from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss
     ref_params = ["epoch_idx", "batch_idx", "batch_per_epoch", "images", "labels", "discriminator", "recognizer", "style_promoter",

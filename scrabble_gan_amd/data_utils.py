@@ -105,13 +105,14 @@ def _pad4(t):
 def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discriminator, recognizer, style_promoter, composite_gan,
                generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
                batch_size, latent_dim, loss_fn, disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path,
-               fake_labels=None, nl=None, verbose=True, sync=True):
+               fake_labels=None, nl=None, verbose=True, sync=True, fuse_passes=True):
     """One optimisation step (data_utils.py:358-473).
 
     Extra keyword arguments (not in the reference): `fake_labels` overrides the host draw of :386-387
     (parity tests, data-parallel ranks that received their shard from rank 0); `nl` maps pass names
     ('G.style','G.up','D.fake','D.real','S.fake','S.style','S.real') to explicit NonLocalBlock
-    kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync.
+    kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync; `fuse_passes=False`
+    keeps every reference call a separate pass even when the input widths match.
     """
     G = composite_gan.generator
     D, R, S = discriminator, recognizer, style_promoter
@@ -150,38 +151,74 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
             nl.update({name: d for (name, _), d in zip(todo, drawn)})
 
     # ---- forward passes, all with the pre-update weights (:398-415) ----
+    # The reference calls D twice, S three times and R twice per step.  Where the inputs have the same width
+    # (always for the fixed-shape configs) those calls ride in ONE pass over the concatenated batch: D and S have
+    # no BatchNorm and the frozen R normalises with moving statistics, so samples are independent and the result is
+    # the same; each call keeps its own NonLocalBlock kernels (passes may be re-ordered).
     x_f, ctx_g = G.forward(style, fake_t, nl.get("G.style"), nl.get("G.up"), training=True)
-    d_f, ctx_df = D.forward(x_f, nl.get("D.fake"))
-    s_f, ctx_sf = S.forward(x_f, nl.get("S.fake"))
-    r_f, ctx_rf = R.forward(x_f, fake_t, ctc_input_length(L_f), L_f, training=True)
-    d_r, ctx_dr = D.forward(images, nl.get("D.real"))
-    s_my, ctx_smy = S.forward(style, nl.get("S.style"))
-    s_r, _ = S.forward(images, nl.get("S.real"))
-    r_r, ctx_rr = R.forward(images, labels_t, ctc_input_length(L_r), L_r, training=True)
+    B = x_f.shape[0]
+    il_f, il_r = ctc_input_length(L_f), ctc_input_length(L_r)
+    fuse = fuse_passes and x_f.shape == images.shape
+    if fuse:
+        (d_f, d_r), ctx_D, _ = D.forward_multi([x_f, images], [nl.get("D.fake"), nl.get("D.real")])
+        fuse_style = style.shape == x_f.shape
+        if fuse_style:
+            (s_f, s_my, s_r), ctx_S, _ = S.forward_multi([x_f, style, images], [nl.get("S.fake"), nl.get("S.style"), nl.get("S.real")])
+        else:
+            (s_f, s_r), ctx_S, _ = S.forward_multi([x_f, images], [nl.get("S.fake"), nl.get("S.real")])
+            s_my, ctx_smy = S.forward(style, nl.get("S.style"))
+        fuse_r = R.can_merge(True)
+        if fuse_r:
+            (r_f, r_r), ctx_R, _ = R.forward_multi([x_f, images], [fake_t, labels_t], il_f, L_f, training=True)
+        else:
+            r_f, ctx_rf = R.forward(x_f, fake_t, il_f, L_f, training=True)
+            r_r, ctx_rr = R.forward(images, labels_t, il_r, L_r, training=True)
+    else:
+        d_f, ctx_df = D.forward(x_f, nl.get("D.fake"))
+        s_f, ctx_sf = S.forward(x_f, nl.get("S.fake"))
+        r_f, ctx_rf = R.forward(x_f, fake_t, il_f, L_f, training=True)
+        d_r, ctx_dr = D.forward(images, nl.get("D.real"))
+        s_my, ctx_smy = S.forward(style, nl.get("S.style"))
+        s_r, _ = S.forward(images, nl.get("S.real"))
+        r_r, ctx_rr = R.forward(images, labels_t, il_r, L_r, training=True)
 
     # ---- losses, gradient balancing, statistics and the upstream gradients of all four targets (:418-442) ----
     mode = getattr(loss_fn, "mode", None)
     if mode is None:
         raise TypeError("loss_fn must be scrabble_gan_amd.net_loss.hinge or .not_saturating")
     v = [t.reshape(-1) for t in (d_r, d_f, s_my, s_f, s_r)]
+    r_f, r_r = r_f.reshape(-1), r_r.reshape(-1)
     sums = red.all_reduce_sum(ops.loss_sums(*v, r_f, r_r, mode))
     scalars, (gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r) = ops.loss_grads(*v, r_f, mode, bool(apply_gradient_balance), 1.0, sums)
 
     # ---- backward sweeps against the same weight snapshot (:449-468) ----
+    # Each network's flat gradient buffer starts its SUM all-reduce (data parallel; the targets are [B,1]
+    # vectors, SURVEY fact 5) as soon as its sweeps are queued, so the D/R/S exchanges overlap G's backward.
     for m in (D, R, S):
         m.store.zero_grad()
     discriminator.trainable = True
-    # Each network's flat gradient buffer starts its SUM all-reduce (data parallel; the targets are [B,1]
-    # vectors, SURVEY fact 5) as soon as its sweeps are queued, so the D/R/S exchanges overlap G's backward.
-    D.backward(ctx_dr, gD_r, want_dx=False, want_dw=True)
-    D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
+    if fuse:
+        D.backward(ctx_D, torch.cat([gD_f, gD_r]), want_dx=False, want_dw=True)
+    else:
+        D.backward(ctx_dr, gD_r, want_dx=False, want_dw=True)
+        D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
     pending = [red.all_reduce_sum_async(D.store.grad)]
     recognizer.trainable = True
-    R.backward(ctx_rr, torch.ones_like(r_r), want_dx=False, want_dw=True)          # target r_real_logits: CTC on real only
+    ones = torch.ones_like(r_r)                                   # target r_real_logits: CTC on real only
+    if fuse and fuse_r:
+        R.backward(R.slice_ctx(ctx_R, B, 2 * B), ones, want_dx=False, want_dw=True)
+    else:
+        R.backward(ctx_rr, ones, want_dx=False, want_dw=True)
     pending.append(red.all_reduce_sum_async(R.store.grad))
     style_promoter.trainable = True
-    S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
-    S.backward(ctx_sf, gS_f, want_dx=False, want_dw=True)
+    if fuse and fuse_style:
+        S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([gS_f, gS_my]), want_dx=False, want_dw=True)
+    elif fuse:
+        S.backward(S.slice_ctx(ctx_S, 0, B), gS_f, want_dx=False, want_dw=True)
+        S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
+    else:
+        S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
+        S.backward(ctx_sf, gS_f, want_dx=False, want_dw=True)
     pending.append(red.all_reduce_sum_async(S.store.grad))
     g_step = (batch_idx + 1) % disc_iters == 0
     if g_step:
@@ -189,9 +226,15 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         discriminator.trainable = False
         style_promoter.trainable = False
         G.store.zero_grad()
-        dx = D.backward(ctx_df, gG_d, want_dx=True, want_dw=False)
-        ops.add(dx, S.backward(ctx_sf, gG_s, want_dx=True, want_dw=False), out=dx)
-        ops.add(dx, R.backward(ctx_rf, gG_r, want_dx=True, want_dw=False), out=dx)
+        if fuse:
+            dx = D.backward(D.slice_ctx(ctx_D, 0, B), gG_d, want_dx=True, want_dw=False)
+            ops.add(dx, S.backward(S.slice_ctx(ctx_S, 0, B), gG_s, want_dx=True, want_dw=False), out=dx)
+            ctx_rf_ = R.slice_ctx(ctx_R, 0, B) if fuse_r else ctx_rf
+            ops.add(dx, R.backward(ctx_rf_, gG_r, want_dx=True, want_dw=False), out=dx)
+        else:
+            dx = D.backward(ctx_df, gG_d, want_dx=True, want_dw=False)
+            ops.add(dx, S.backward(ctx_sf, gG_s, want_dx=True, want_dw=False), out=dx)
+            ops.add(dx, R.backward(ctx_rf, gG_r, want_dx=True, want_dw=False), out=dx)
         G.backward(ctx_g, dx)
 
     # ---- finish the gradient exchange, then the four updates ----

@@ -149,17 +149,39 @@ class _DownTrunk:
             return nl
         return nn.nonlocal_weights(C, nl_gen, S.device)       # fact 3: fresh orthogonal kernels per call
 
-    def fwd(self, x, S: ParamStore, nl=None, nl_gen=None):
+    def fwd(self, x, S: ParamStore, nl=None, nl_gen=None, segments=None):
+        """`segments` = [(lo, hi, nl_kernels), ...]: batch ranges that are separate NonLocalBlock calls of the
+        reference (each with its own freshly drawn 1x1 kernels) riding in ONE pass of the conv trunk."""
         ctxs = []
         net = x
         for i, n in enumerate(self.names):
             net, c = nn.block_down_fwd(net, S, n, is_last=(i == len(self.names) - 1))
             nlc = None
             if n in self.attn:
-                net, nlc = nn.nonlocal_fwd(net, self._nlw(S, n, self.cout[i], nl, nl_gen), S.p["NL_" + n + ".sigma"])
+                sigma = S.p["NL_" + n + ".sigma"]
+                if segments is None:
+                    net, nlc = nn.nonlocal_fwd(net, self._nlw(S, n, self.cout[i], nl, nl_gen), sigma)
+                else:
+                    out, segc = torch.empty_like(net), []
+                    for lo, hi, nl_seg in segments:
+                        _, cseg = nn.nonlocal_fwd(net[lo:hi], self._nlw(S, n, self.cout[i], nl_seg, nl_gen), sigma, out=out[lo:hi])
+                        segc.append((lo, hi, cseg))
+                    net, nlc = out, ("seg", segc)
             ctxs.append((c, nlc))
         h = ops.gap_fwd(net, relu=True)                         # tf.nn.relu + GlobalAveragePooling2D
         return h, (ctxs, net)
+
+    @staticmethod
+    def slice_ctx(ctx, lo, hi):
+        """The saved context of batch rows [lo, hi) of a multi-segment pass (segment-aligned)."""
+        ctxs, net = ctx
+        out = []
+        for (x, c1), nlc in ctxs:
+            if nlc is not None:
+                assert nlc[0] == "seg"
+                nlc = ("seg", [(a - lo, b - lo, c) for a, b, c in nlc[1] if a >= lo and b <= hi])
+            out.append(((x[lo:hi], c1[lo:hi]), nlc))
+        return out, net[lo:hi]
 
     def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool):
         ctxs, net = ctx
@@ -172,7 +194,14 @@ class _DownTrunk:
                 dnlw = None
                 if self.nl_mode == "persistent" and want_dw:
                     dnlw = {k: S.g["NL_" + n + "." + k] for k in ("theta", "phi", "g", "o")}
-                d = nn.nonlocal_bwd(nlc, d, S.p["NL_" + n + ".sigma"], dsig, dnlw)
+                sigma = S.p["NL_" + n + ".sigma"]
+                if isinstance(nlc, tuple) and len(nlc) == 2 and nlc[0] == "seg":
+                    dn = torch.empty_like(d)
+                    for lo, hi, cseg in nlc[1]:
+                        nn.nonlocal_bwd(cseg, d[lo:hi], sigma, dsig, dnlw, out=dn[lo:hi])
+                    d = dn
+                else:
+                    d = nn.nonlocal_bwd(nlc, d, sigma, dsig, dnlw)
             d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw)
         return d
 
@@ -193,6 +222,24 @@ class DiscriminatorModel(_Model):
         h, tctx = self.trunk.fwd(x, self.store, nl, self.nl_gen)
         logits = ops.dense_fwd(h, self.store.p["dense.w"])                     # [B,1]
         return logits, (tctx, h)
+
+    def forward_multi(self, xs, nls):
+        """Several reference calls of this model (same input width) as ONE pass over the concatenated batch: the
+        nets have no BatchNorm, so samples are independent and the result equals separate calls; only the
+        NonLocalBlock kernels differ per call (`nls[i]`).  -> ([logits_i], ctx, [(lo_i, hi_i)])."""
+        xs = [_as_nhwc1(x, self.device) for x in xs]
+        bounds, lo = [], 0
+        for x in xs:
+            bounds.append((lo, lo + x.shape[0]))
+            lo += x.shape[0]
+        segs = [(a, b, nl) for (a, b), nl in zip(bounds, nls)]
+        h, tctx = self.trunk.fwd(torch.cat(xs, 0), self.store, None, self.nl_gen, segments=segs)
+        logits = ops.dense_fwd(h, self.store.p["dense.w"])
+        return [logits[a:b] for a, b in bounds], (tctx, h), bounds
+
+    def slice_ctx(self, ctx, lo, hi):
+        tctx, h = ctx
+        return self.trunk.slice_ctx(tctx, lo, hi), h[lo:hi]
 
     def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool):
         tctx, h = ctx
@@ -391,6 +438,34 @@ class RecognizerModel(_Model):
         logits = ops.dense_fwd(feat, p["dense.w"], p["dense.b"]).view(B, T, self.classes)     # Dense (softmax fused below)
         loss, dlogits = ops.softmax_ctc(logits, labels, int(input_length), int(label_length), need_grad)
         return loss, (acts, feat, dlogits, (B, T))
+
+    def can_merge(self, training=True) -> bool:
+        """Calls may share one pass only while BatchNorm is in inference mode (per-sample independent)."""
+        return type(self) is RecognizerModel and not (training and self.trainable)
+
+    def forward_multi(self, xs, labels_list, input_length, label_length, training=True):
+        xs = [_as_nhwc1(x, self.device) for x in xs]
+        labs = [_as_labels(l, self.device) for l in labels_list]
+        bounds, lo = [], 0
+        for x in xs:
+            bounds.append((lo, lo + x.shape[0]))
+            lo += x.shape[0]
+        loss, ctx = self.forward(torch.cat(xs, 0), torch.cat(labs, 0), input_length, label_length, training)
+        return [loss[a:b] for a, b in bounds], ctx, bounds
+
+    @staticmethod
+    def slice_ctx(ctx, lo, hi):
+        acts, feat, dlogits, (B, T) = ctx
+        out = []
+        for rec in acts:
+            r = {"in": rec["in"][lo:hi], "a": rec["a"][lo:hi]}
+            if "idx" in rec:
+                r["idx"] = rec["idx"][lo:hi]
+            if "bn" in rec:
+                assert rec["bn"][0] == "infer"
+                r["bn"] = ("infer", rec["bn"][1][lo:hi])
+            out.append(r)
+        return out, feat.view(B, T, -1)[lo:hi].reshape((hi - lo) * T, -1), dlogits[lo:hi], (hi - lo, T)
 
     def backward(self, ctx, upstream, want_dx: bool, want_dw: bool):
         """upstream [B] = d(target)/d(cost_b).  Returns d(target)/d(images) if want_dx."""

@@ -204,7 +204,7 @@ def nonlocal_weights_batch(requests, device) -> List[Dict[str, torch.Tensor]]:
     return out
 
 
-def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor):
+def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor, out=None):
     B, H, W, C = x.shape
     w_t, w_p, w_g, w_o = (nlw[k].view(1, 1, *nlw[k].shape[-2:]) for k in ("theta", "phi", "g", "o"))
     theta = ops.conv2d_fwd(x, w_t)                                         # :38-41
@@ -213,11 +213,11 @@ def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor):
     Nq, Nk = H * W, (H // 2) * (W // 2)
     o, lse = ops.attention_fwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2))   # :51-52,61
     oc = ops.conv2d_fwd(o.view(B, H, W, C // 2), w_o)                      # :62-65
-    out = ops.scale_add(oc, x, sigma.view(1))                              # :67
+    out = ops.scale_add(oc, x, sigma.view(1), out=out)                     # :67
     return out, (x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o))
 
 
-def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Optional[Dict[str, torch.Tensor]] = None):
+def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Optional[Dict[str, torch.Tensor]] = None, out=None):
     x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o) = ctx
     B, H, W, C = x.shape
     Nq, Nk = H * W, (H // 2) * (W // 2)
@@ -237,7 +237,7 @@ def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Opt
     dx = ops.conv2d_bwd_data(dth, w_t, (H, W))
     ops.conv2d_bwd_data(dph_f, w_p, (H, W), out=dx, accum=True)
     ops.conv2d_bwd_data(dg_f, w_g, (H, W), out=dx, accum=True)
-    return ops.add(dx, dout, out=dx)
+    return ops.add(dx, dout, out=dx if out is None else out)
 
 
 # --------------------------------------------------------------------------------------------

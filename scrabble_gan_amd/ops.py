@@ -250,9 +250,10 @@ def gap_bwd(dout, x, relu=True):
     return dx
 
 
-def scale_add(o, x, sigma):
-    _chk(o, x, sigma)
-    out = torch.empty_like(x)
+def scale_add(o, x, sigma, out=None):
+    _chk(o, x, sigma, out)
+    if out is None:
+        out = torch.empty_like(x)
     call("sg_scale_add", _p(o), _p(x), _p(sigma), _p(out), x.numel(), _stream())
     return out
 

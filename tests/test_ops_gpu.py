@@ -65,8 +65,11 @@ def test_conv2d_fwd_bwd(dev, gen, B, H, W, Cin, Cout, k, same):
     dxg = ops.conv2d_bwd_data(dyg, wg, (H, W), mask=xg, same=same)
     close(dxg, x.grad, name="bwd_data")
     dwg = torch.zeros_like(wg)
-    ops.conv2d_bwd_weight(xg, dyg, dwg, same=same, relu_in=True)
+    dbf = torch.zeros_like(bg) if Cout > 1 else None          # bias-grad fused into the weight-grad sweep
+    ops.conv2d_bwd_weight(xg, dyg, dwg, same=same, relu_in=True, db=dbf)
     close(dwg, w.grad, tol=5e-5, name="bwd_weight")
+    if dbf is not None:
+        close(dbf, b.grad, tol=5e-5, name="fused bias_grad")
     dbg = torch.zeros_like(bg)
     ops.bias_grad(dyg, dbg)
     close(dbg, b.grad, tol=5e-5, name="bias_grad")

@@ -7,8 +7,9 @@
 //   B (filter slice) : Bs[k][n]; either a straight float4 copy ([K,N] row-major weights) or the
 //                      same transposing loader as A when the weights are stored [N][K]
 //   MFMA             : 32x32x2 f32, lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]
-//   pipeline         : double-buffered LDS, next k-tile prefetched into registers under the MFMAs,
-//                      one barrier per k-tile; 2 workgroups (8 waves) resident per CU
+//   pipeline         : double-buffered LDS (BK = 16 -> 33 KB), next k-tile's global loads / LDS stores
+//                      interleaved under the MFMAs, one barrier per k-tile; 3-4 workgroups per CU
+//                      (measured: staggering co-resident workgroups changes nothing; MFMA pipe 80 % busy)
 //   epilogue         : bias(+bias2), ReLU-backward mask, accumulate, ReLU, straight from the
 //                      accumulators (lanes 0-31 of a register write one 128-byte row segment)
 #include "sg_conv.h"

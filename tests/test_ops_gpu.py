@@ -269,7 +269,7 @@ def test_attention(dev, gen, Nq, Nk):
     close(dg, g.grad, tol=5e-5, name="dg")
 
 
-@pytest.mark.parametrize("L", [1, 3, 10])
+@pytest.mark.parametrize("L", [1, 3, 10, 23])      # 23: the widest bucket of config c4 (T = 91, S = 47, > 64 KB of LDS)
 def test_softmax_ctc(dev, gen, L):
     from scrabble_gan_amd import ops
     B, C = 4, 53

@@ -1,0 +1,51 @@
+"""The host loop end to end on the GPU: gin config -> factories -> train() on synthetic variable-width buckets
+(one word length per batch, L in [1,10]) -> 16-column summaries and per-epoch G/R weight files; and the widest
+bucket of config c4 (L = 23) through every network."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_synthetic_writes_summaries_and_checkpoints(dev, tmp_path, monkeypatch):
+    from scrabble_gan_amd import gin_config as gin, main as M
+    cfg = tmp_path / "cfg.gin"
+    base = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "scrabble_gan_mi355x.gin")).read()
+    cfg.write_text(base + "\nio.base_path = '%s/'\nshared_specs.batch_size = 4\nshared_specs.num_gen = 4\n" % tmp_path)
+    gin.clear_config()
+    M.main(["--gin", str(cfg), "--synthetic", "--steps", "3", "--epochs", "1"])
+    out = tmp_path / "run" / "output"
+    rows = (out / "batch_summary.txt").read_text().strip().split("\n")
+    assert rows[0].startswith("disc_loss;disc_loss_real") and len(rows) == 4
+    for r in rows[1:]:
+        cols = r.split(";")
+        assert len(cols) == 16 and all(np.isfinite(float(c)) for c in cols)
+    assert len((out / "epoch_summary.txt").read_text().strip().split("\n")) == 2
+    for net in ("generator", "recognizer"):
+        assert (tmp_path / "run" / "checkpoints" / net / "1" / "cktp-1.safetensors").exists()
+    gin.clear_config()
+
+
+def test_widest_bucket_and_bilstm_recognizer_step(dev):
+    """L_r = 23 real words, L_f = 4 fakes, the BiLSTM recognizer with device-drawn dropout: one finite step."""
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
+    NA.configure(device=dev, seed=2)
+    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+    D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+    R = NA.make_my_recognizer((32, 160, 1), None, 53, vis_model=False)
+    S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+    gan = NA.make_gan(G, D, R, S, vis_model=False)
+    opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(3)] + [optimizers.RMSprop(2e-4)]
+    images, labels, my_imgs = DU.synthetic_batch(2, 23, seed=5)
+    words = DU.synthetic_random_words(23, 20, seed=5)
+    fake = np.array(words[3][:2], np.int32)
+    before = G.store.flat.clone()
+    out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[3], opts[2], my_imgs, 2, 128, net_loss.hinge, 1, 1,
+                        words, 23, "", fake_labels=fake, verbose=False)
+    assert len(out) == 16 and all(np.isfinite(float(v)) for v in out)
+    assert torch.isfinite(G.store.flat).all() and not torch.equal(before, G.store.flat)
+    img = G([my_imgs, np.array(words[22][:2], np.int32)], training=False)            # inference path, 23-char words
+    assert tuple(img.shape) == (2, 32, 368, 1) and img.abs().max().item() <= 1.0

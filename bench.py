@@ -69,9 +69,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    reducer = sdist.init_from_env("nccl")
+    # SG_DIST_BACKEND=gloo SG_FORCE_DEVICE=0 rehearse the multi-rank path with several ranks on ONE GPU (RCCL needs
+    # one device per rank); the driver's runs use the defaults: nccl, one GPU per rank.
+    backend = os.environ.get("SG_DIST_BACKEND", "nccl")
+    local_rank = int(os.environ.get("SG_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if backend != "nccl":
+        torch.cuda.set_device(local_rank)
+    reducer = sdist.init_from_env(backend)
     rank = getattr(reducer, "rank", 0)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas

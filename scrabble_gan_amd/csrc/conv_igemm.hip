@@ -324,9 +324,8 @@ int sg_launch_igemm(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
     return bk_env == 16 ? launch_cfg<128, 128, 2, 2, 16, 3>(a, b_nk, s) : launch_cfg<128, 128, 2, 2>(a, b_nk, s);
   }
   if (a.N > 32) {
-    // N <= 64: 256x64 tiles keep the 64x64-per-wave shape (4 MFMAs per 4 LDS reads) of the 128x128 config
-    const long M = (long)a.Bn * a.Hg * a.Wg;
-    if (tile_env == 256 && M >= 256L * 1024) return launch_cfg<256, 64, 4, 1, 16, 3>(a, b_nk, s);   // measured: no gain at K=576
+    // (measured and dropped: 256x64 tiles for N <= 64, 2-wave workgroups with 128x64 wave tiles, s_setprio around the
+    //  MFMA clusters, staggered workgroup starts -- none beat this configuration)
     return bk_env == 16 ? launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s) : launch_cfg<128, 64, 2, 2>(a, b_nk, s);
   }
   return launch_cfg<128, 32, 4, 1>(a, b_nk, s);

@@ -14,6 +14,7 @@
 //                      accumulators (lanes 0-31 of a register write one 128-byte row segment)
 #include "sg_conv.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -113,28 +114,33 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   float4 b_reg[B_P];
   int lt = kt_begin / kchunks, lc0 = (kt_begin - (kt_begin / kchunks) * kchunks) * BK;   // (tap, channel offset) of the next k-tile to fetch
 
+  // Branch-free loads: an out-of-range lane reads element 0 (always mapped) and the value is replaced by zero with
+  // selects, so the whole k-tile body stays ONE basic block and the scheduler can interleave VMEM / LDS / MFMA.
+  auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
   auto load_a = [&]() {
     const int tap_off = (p.taps[lt].dy * p.Wa + p.taps[lt].dx) * p.Ca + lc0;
     const bool cok = lc0 + 4 * kc < p.Ca;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (((a_mask[i] >> lt) & 1u) && cok) v = *reinterpret_cast<const float4*>(p.a + (a_base[i] + tap_off));
-      a_reg[i] = v;
+      const bool ok = ((a_mask[i] >> lt) & 1u) && cok;
+      const int off = ok ? a_base[i] + tap_off : 0;
+      a_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(p.a + off));
     }
   };
   auto load_b = [&]() {
     const float* wt = p.w + p.taps[lt].w_off;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_NK) {
-        if (b_ok[i] && lc0 + 4 * kc < p.Ca) v = *reinterpret_cast<const float4*>(wt + (b_off[i] + lc0));
+        const bool ok = b_ok[i] && lc0 + 4 * kc < p.Ca;
+        const int off = ok ? b_off[i] + lc0 : 0;
+        b_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(wt + off));
       } else {
         const int k = tid / (BN / 4) + i * BKN_RPP;
-        if (b_ok[i] && lc0 + k < p.Ca) v = *reinterpret_cast<const float4*>(wt + (b_off[i] + lc0 * p.ldw));
+        const bool ok = b_ok[i] && lc0 + k < p.Ca;
+        const int off = ok ? b_off[i] + lc0 * p.ldw : 0;
+        b_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(wt + off));
       }
-      b_reg[i] = v;
     }
     lc0 += BK;                       // advance the fetch cursor
     if (lc0 >= p.Ca) { lc0 = 0; ++lt; }
@@ -193,14 +199,13 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   }
   __syncthreads();
 
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
+  // One k-tile: the next tile's global loads are issued after the first MFMA groups and its LDS stores before the
+  // last ones, so address arithmetic, VMEM issue and LDS writes all sit in MFMA shadows (each 32x32x2 f32 MFMA
+  // leaves ~56 of its 64 cycles of vector issue free).  `more` is a compile-time tag: the last tile is peeled.
+  auto k_tile = [&](int buf, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
     const float* as = As + buf * BK * LDA + khalf * LDA + a_col;
     const float* bs = Bs + buf * BK * LDB + khalf * LDB + b_col;
-    // The next k-tile's global loads are issued after the first MFMA groups and its LDS stores before
-    // the last ones, so address arithmetic, VMEM issue and LDS writes all sit in MFMA shadows
-    // (each 32x32x2 f32 MFMA leaves ~56 of its 64 cycles of vector issue free).
     float af[2][TM], bf[2][TN];     // fragment double buffer: k-step kk+1 is read from LDS under the MFMAs of kk
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = as[i * 32];
@@ -220,13 +225,17 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-      if (kk == 0 && more) load_a();
-      if (kk == 1 && more) load_b();
-      if (kk == KS - 5 && more) store_a(buf ^ 1);
-      if (kk == KS - 3 && more) store_b(buf ^ 1);
+      if constexpr (more) {
+        if (kk == 0) load_a();
+        if (kk == 1) load_b();
+        if (kk == KS - 5) store_a(buf ^ 1);
+        if (kk == KS - 3) store_b(buf ^ 1);
+      }
     }
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < KT; ++kt) k_tile(kt & 1, std::true_type{});
+  if (KT > 0) k_tile((KT - 1) & 1, std::false_type{});
 
   // ---- epilogue ----
   const bool accum = (p.flags & SG_ACCUM) != 0;

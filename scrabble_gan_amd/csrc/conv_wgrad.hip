@@ -8,10 +8,14 @@
 // added to dW with float atomics (one 128-byte row segment per half-wave: full atomic rate).
 #include "sg_conv.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BC, int BN, int WM, int WN, int BK, int OCC>
+// IDENT: both operands live on the base grid with unit sampling stride (every stride-1 Conv2D weight-grad): their
+// addresses are linear in the pixel index, so the k-loop needs one add per load; only the tap validity of P still
+// follows a (y, x) cursor.  The general form (strided sampling: transposed convolutions) keeps full cursors.
+template <int BC, int BN, int WM, int WN, int BK, int OCC, bool IDENT>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgradArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
@@ -58,21 +62,29 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
 #pragma unroll
   for (int i = 0; i < Q_P; ++i) decode(m_begin + tid / (BN / 4) + i * Q_RPP, qb[i], qy[i], qx[i]);
   int m_next = m_begin;          // first pixel of the next k-tile to fetch
+  // advancing a cursor by BK pixels without branches: BK = adv_b*HW + adv_y*Wg + adv_x (uniform, computed once),
+  // then at most one wrap per coordinate
+  const int adv_b = BK / HW, adv_r = BK - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
   auto advance = [&](int& bb, int& yy, int& xx) {
-    xx += BK;
-    while (xx >= p.Wg) { xx -= p.Wg; ++yy; }
-    while (yy >= p.Hg) { yy -= p.Hg; ++bb; }
+    xx += adv_x;
+    const int cx = xx >= p.Wg ? 1 : 0;
+    xx -= cx * p.Wg;
+    yy += adv_y + cx;
+    const int cy = yy >= p.Hg ? 1 : 0;
+    yy -= cy * p.Hg;
+    bb += adv_b + cy;
   };
+  auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
 
+  // branch-free loads (an out-of-range lane reads element 0 and is zeroed by selects): one basic block per k-tile
   auto load_p = [&]() {
 #pragma unroll
     for (int i = 0; i < P_P; ++i) {
       const int m = m_next + tid / (BC / 4) + i * P_RPP;
       const int iy = py[i] * p.p_sy + dy, ix = px[i] * p.p_sx + dx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end && p_cok && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp)
-        v = *reinterpret_cast<const float4*>(p.p + (((pb[i] * p.Hp + iy) * p.Wp + ix) * p.Cp + pc));
-      p_reg[i] = v;
+      const bool ok = m < m_end && p_cok && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp;
+      const int off = !ok ? 0 : IDENT ? (m + dy * p.Wp + dx) * p.Cp + pc : ((pb[i] * p.Hp + iy) * p.Wp + ix) * p.Cp + pc;
+      p_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(p.p + off));
       advance(pb[i], py[i], px[i]);
     }
   };
@@ -82,12 +94,12 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
 #pragma unroll
     for (int i = 0; i < Q_P; ++i) {
       const int m = m_next + tid / (BN / 4) + i * Q_RPP;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end && q_cok)
-        v = *reinterpret_cast<const float4*>(p.q + (((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn));
+      const bool ok = m < m_end && q_cok;
+      const int off = !ok ? 0 : IDENT ? m * p.Cq + qn : ((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn;
+      const float4 v = sel4(ok, *reinterpret_cast<const float4*>(p.q + off));
       q_reg[i] = v;
       if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-      advance(qb[i], qy[i], qx[i]);
+      if (!IDENT) advance(qb[i], qy[i], qx[i]);
     }
     m_next += BK;
   };
@@ -126,9 +138,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     store_q(0);
   }
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
+  auto k_tile = [&](int buf, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;       // the last tile (nothing left to prefetch) is peeled
     const float* ps = Ps + buf * BK * BC + khalf * BC + a_col;
     const float* qs = Qs + buf * BK * BN + khalf * BN + b_col;
     float af[2][TM], bf[2][TN];
@@ -151,13 +162,17 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       // next k-tile: global loads right after the first MFMA groups, LDS stores before the last ones
-      if (kk == 0 && more) load_p();
-      if (kk == 1 && more) load_q();
-      if (kk == KS - 5 && more) store_p(buf ^ 1);
-      if (kk == KS - 3 && more) store_q(buf ^ 1);
+      if constexpr (more) {
+        if (kk == 0) load_p();
+        if (kk == 1) load_q();
+        if (kk == KS - 5) store_p(buf ^ 1);
+        if (kk == KS - 3) store_q(buf ^ 1);
+      }
     }
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < KT; ++kt) k_tile(kt & 1, std::true_type{});
+  if (KT > 0) k_tile((KT - 1) & 1, std::false_type{});
 
   if (do_bias) {      // (block-uniform) reduce the per-thread column sums over the Q_RPP row lanes, one atomic per column
     float4* red = reinterpret_cast<float4*>(smem);
@@ -191,6 +206,10 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   }
 }
 
+static inline bool wgrad_ident(const SgWgradArgs& a) {
+  return a.p_sy == 1 && a.p_sx == 1 && a.q_sy == 1 && a.q_sx == 1 && a.Hp == a.Hg && a.Wp == a.Wg && a.Hq == a.Hg && a.Wq == a.Wg;
+}
+
 template <int BC, int BN, int WM, int WN, int BK = 32, int OCC = 2>
 static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
@@ -204,8 +223,10 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;
   a.mchunk = (int)mchunk;
-  hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC>), dim3((unsigned)(combos * nchunks)),
-                     dim3(WM * WN * 64), 0, s, a);
+  if (wgrad_ident(a))
+    hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true>), dim3((unsigned)(combos * nchunks)), dim3(WM * WN * 64), 0, s, a);
+  else
+    hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false>), dim3((unsigned)(combos * nchunks)), dim3(WM * WN * 64), 0, s, a);
   return sg_launch_status();
 }
 

@@ -44,8 +44,8 @@ def build():
     yb.backward(dyb)
     out.update(cbn_x=xb, cbn_z=z, cbn_wg=wg, cbn_wb=wb, cbn_y=yb, cbn_dy=dyb, cbn_dx=xb.grad)
     # NonLocalBlock
-    xn = r(2, 4, 8, 16).requires_grad_(True)
-    nl = O.init_nonlocal(16, g)
+    xn = r(2, 4, 8, 64).requires_grad_(True)
+    nl = O.init_nonlocal(64, g)
     sig = torch.tensor(0.4, dtype=D)
     yn = O.nonlocal_block(xn, nl["theta"], nl["phi"], nl["g"], nl["o"], sig)
     dyn = r(*yn.shape)

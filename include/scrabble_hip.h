@@ -40,8 +40,9 @@ int sg_conv2d_fwd(const float* x, const float* w, const float* bias, const float
  * SG_ACCUM adds the previous dx AFTER masking (sum of the main and shortcut branches) */
 int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx,
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
-/* dw += conv_weight_grad(relu?(x), dy) ; dbias (nullable, Cout > 1) += sum over pixels of dy, fused into the same sweep */
-int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias,
+/* dw += conv_weight_grad(relu?(x), dy) ; dbias (nullable, Cout > 1) += sum over pixels of dy, fused into the same sweep;
+ * sample_scale (nullable, [B]) weights sample b's contribution to dw / dbias by sample_scale[b] (shared backward sweeps) */
+int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
 /* ---- layers.Conv2DTranspose(padding='same', strides=(sh,sw)) (resnet_ops.py:57,69) ------- */
@@ -124,7 +125,9 @@ int sg_loss_sums(const float* d_r, const float* d_f, const float* s_my, const fl
                  const float* r_r, int B, int mode, double* sums, void* stream);
 int sg_loss_grads(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, const float* r_f,
                   int B, int mode, int balance, float alpha, const double* sums, float* scalars16, float* gD_r, float* gD_f,
-                  float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, void* stream);
+                  float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, float* shD3, float* shS3, void* stream);
+/* shD3 / shS3 (nullable, [3,B]): upstream u, weight-gradient scale gD_f/u and image-gradient scale gG_d/u of the ONE shared
+ * backward sweep through D(x_f) / S(x_f) that serves both sum(d_loss) and sum(g_final) (backprop is linear per sample) */
 
 /* out7 [7,B] = d_loss, d_loss_real, d_loss_fake, g_loss, s_loss, s_a, s_b per sample (the 7 tensors loss_fn returns) */
 int sg_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, int B, int mode,

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     }
   };
   const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;     // one (tap, c-tile) column of workgroups sums dy
+  const bool qscaled = p.qscale != nullptr;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_q = [&]() {
 #pragma unroll
@@ -96,10 +97,14 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
       const int m = m_next + tid / (BN / 4) + i * Q_RPP;
       const bool ok = m < m_end && q_cok;
       const int off = !ok ? 0 : IDENT ? m * p.Cq + qn : ((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn;
-      const float4 v = sel4(ok, *reinterpret_cast<const float4*>(p.q + off));
+      float4 v = sel4(ok, *reinterpret_cast<const float4*>(p.q + off));
+      if (qscaled) {                                   // block-uniform
+        const float sc = p.qscale[ok ? qb[i] : 0];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      }
       q_reg[i] = v;
       if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-      if (!IDENT) advance(qb[i], qy[i], qx[i]);
+      if (!IDENT || qscaled) advance(qb[i], qy[i], qx[i]);
     }
     m_next += BK;
   };
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
     const int rem = (int)(m - (long)b * HW);
     const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
     float4 q = *reinterpret_cast<const float4*>(p.w + (size_t)m * p.C + 4 * cq);
+    if (p.qscale) { const float sc = p.qscale[b]; q.x *= sc; q.y *= sc; q.z *= sc; q.w *= sc; }
     if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
     qsum.x += q.x; qsum.y += q.y; qsum.z += q.z; qsum.w += q.w;
 #pragma unroll
@@ -337,7 +343,7 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // C-ABI entry points
 // ------------------------------------------------------------------------------------------
-extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int H, int W,
+extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale, int B, int H, int W,
                                     int Cin, int Cout, int kh, int kw, int pad_same, int flags,
                                     void* stream) {
   if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
@@ -346,14 +352,14 @@ extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
   hipStream_t s = (hipStream_t)stream;
   if (Cin == 1) {  // dW[t, co] = sum_m relu?(x)[pix+tap] * dy[m, co]
     SgThinArgs a{};
-    a.a = x; a.w = dy; a.out = dw; a.bias = dbias; a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.C = Cout;
+    a.a = x; a.w = dy; a.out = dw; a.bias = dbias; a.qscale = sample_scale; a.Bn = B; a.Ha = H; a.Wa = W; a.Hg = Ho; a.Wg = Wo; a.C = Cout;
     a.ntaps = kh * kw; a.flags = flags;
     for (int ky = 0; ky < kh; ++ky)
       for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cout};
     return launch_thin_wgrad(a, s);
   }
   if (Cout == 1) {  // dW[t, ci] = sum_m' x[m', ci] * dy[m' - tap]
-    if (dbias) return SG_ERR_UNSUPPORTED;   // the C-channel operand is x here: use sg_bias_grad on dy
+    if (dbias || sample_scale) return SG_ERR_UNSUPPORTED;   // the C-channel operand is x here: use sg_bias_grad on dy
     SgThinArgs a{};
     a.a = dy; a.w = x; a.out = dw; a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Hg = H; a.Wg = W; a.C = Cin;
     a.ntaps = kh * kw; a.flags = (flags & SG_RELU_IN) ? 16 : 0;
@@ -362,7 +368,7 @@ extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
     return launch_thin_wgrad(a, s);
   }
   SgWgradArgs a{};
-  a.p = x; a.q = dy; a.dw = dw; a.dbias = dbias;
+  a.p = x; a.q = dy; a.dw = dw; a.dbias = dbias; a.qscale = sample_scale;
   a.Bn = B; a.Hp = H; a.Wp = W; a.Cp = Cin; a.p_sy = 1; a.p_sx = 1;
   a.Hq = Ho; a.Wq = Wo; a.Cq = Cout; a.q_sy = 1; a.q_sx = 1; a.Hg = Ho; a.Wg = Wo;
   a.ntaps = kh * kw; a.flags = flags;

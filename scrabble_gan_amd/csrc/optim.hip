@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_loss_sums(const float* d_r, const float
 __global__ __launch_bounds__(256) void k_loss_grads(const float* d_r, const float* d_f, const float* s_my, const float* s_f,
                                                     const float* s_r, const float* r_f, int B, int mode, int balance, float alpha,
                                                     const double* sums, float* scalars, float* gD_r, float* gD_f, float* gS_my,
-                                                    float* gS_f, float* gG_d, float* gG_s, float* gG_r) {
+                                                    float* gS_f, float* gG_d, float* gG_s, float* gG_r, float* shD, float* shS) {
   const double n = sums[11];
   const double g_mean = sums[3] / n, r_mean = sums[7] / n;
   const double g_var = fmax(sums[9] / n - g_mean * g_mean, 0.0), r_var = fmax(sums[10] / n - r_mean * r_mean, 0.0);
@@ -222,6 +222,21 @@ __global__ __launch_bounds__(256) void k_loss_grads(const float* d_r, const floa
     gG_d[b] = (float)(wg * dg_dd);
     gG_s[b] = (float)(wg * dg_ds);
     gG_r[b] = (float)wr;
+    // Shared backward sweep through D(x_f) / S(x_f): backprop is linear per sample, so ONE sweep with upstream u_b
+    // serves both targets -- the weight gradients of sum(d_loss) weight sample b by gD_f/u_b, the image gradient of
+    // sum(g_final) scales by gG_d/u_b.  u_b is the larger of the two in magnitude (both factors <= 1).
+    if (shD) {
+      const float a = gD_f[b], c = gG_d[b];
+      const float u = (fabsf(c) >= fabsf(a)) ? c : a;
+      const float inv = u != 0.f ? 1.f / u : 0.f;
+      shD[b] = u != 0.f ? u : 1.f; shD[B + b] = a * inv; shD[2 * B + b] = c * inv;
+    }
+    if (shS) {
+      const float a = gS_f[b], c = gG_s[b];
+      const float u = (fabsf(c) >= fabsf(a)) ? c : a;
+      const float inv = u != 0.f ? 1.f / u : 0.f;
+      shS[b] = u != 0.f ? u : 1.f; shS[B + b] = a * inv; shS[2 * B + b] = c * inv;
+    }
   }
 }
 
@@ -234,11 +249,12 @@ extern "C" int sg_loss_sums(const float* d_r, const float* d_f, const float* s_m
 
 extern "C" int sg_loss_grads(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r,
                              const float* r_f, int B, int mode, int balance, float alpha, const double* sums, float* scalars,
-                             float* gD_r, float* gD_f, float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, void* stream) {
+                             float* gD_r, float* gD_f, float* gS_my, float* gS_f, float* gG_d, float* gG_s, float* gG_r, float* shD,
+                             float* shS, void* stream) {
   if (!d_r || !d_f || !s_my || !s_f || !s_r || !r_f || !sums || !scalars || !gD_r || !gD_f || !gS_my || !gS_f || !gG_d || !gG_s || !gG_r)
     return SG_ERR_ARG;
   hipLaunchKernelGGL(k_loss_grads, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, r_f, B, mode,
-                     balance, alpha, sums, scalars, gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r);
+                     balance, alpha, sums, scalars, gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r, shD, shS);
   return sg_launch_status();
 }
 

@@ -34,6 +34,7 @@ struct SgWgradArgs {
   const float* p;      // tap-shifted operand, NHWC [Bn, Hp, Wp, Cp]
   const float* q;      // base-grid operand,   NHWC [Bn, Hq, Wq, Cq] sampled at (q_sy*yg, q_sx*xg)
   float* dw;           // per tap a [Cp x Cq] row-major matrix at dw + taps[t].w_off
+  const float* qscale; // nullable: per-sample factor [Bn] applied to the Q rows (weights the samples' contributions to dW / dbias)
   float* dbias;        // nullable: dbias[n] += sum_m Q[m][n] (bias gradient when Q is dy), done by the tap-0 / c-tile-0 workgroups
   int Bn, Hp, Wp, Cp, p_sy, p_sx;
   int Hq, Wq, Cq, q_sy, q_sx;
@@ -49,6 +50,7 @@ struct SgThinArgs {
   float* out;
   const float* bias;
   const float* mask;
+  const float* qscale; // thin weight-grad only: per-sample factor on the C-channel operand
   int Bn, Ha, Wa, Hg, Wg, C;
   int ntaps, flags;
   SgTap taps[SG_MAX_TAPS];

@@ -105,14 +105,15 @@ def _pad4(t):
 def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discriminator, recognizer, style_promoter, composite_gan,
                generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
                batch_size, latent_dim, loss_fn, disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path,
-               fake_labels=None, nl=None, verbose=True, sync=True, fuse_passes=True):
+               fake_labels=None, nl=None, verbose=True, sync=True, fuse_passes=True, share_backward=True):
     """One optimisation step (data_utils.py:358-473).
 
     Extra keyword arguments (not in the reference): `fake_labels` overrides the host draw of :386-387
     (parity tests, data-parallel ranks that received their shard from rank 0); `nl` maps pass names
     ('G.style','G.up','D.fake','D.real','S.fake','S.style','S.real') to explicit NonLocalBlock
     kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync; `fuse_passes=False`
-    keeps every reference call a separate pass even when the input widths match.
+    keeps every reference call a separate pass even when the input widths match; `share_backward=False` runs the
+    weight-gradient and image-gradient sweeps through D(x_f) / S(x_f) separately, as the reference's tapes do.
     """
     G = composite_gan.generator
     D, R, S = discriminator, recognizer, style_promoter
@@ -189,19 +190,34 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     v = [t.reshape(-1) for t in (d_r, d_f, s_my, s_f, s_r)]
     r_f, r_r = r_f.reshape(-1), r_r.reshape(-1)
     sums = red.all_reduce_sum(ops.loss_sums(*v, r_f, r_r, mode))
-    scalars, (gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r) = ops.loss_grads(*v, r_f, mode, bool(apply_gradient_balance), 1.0, sums)
+    scalars, (gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r, shD, shS) = ops.loss_grads(*v, r_f, mode, bool(apply_gradient_balance), 1.0, sums)
 
     # ---- backward sweeps against the same weight snapshot (:449-468) ----
     # Each network's flat gradient buffer starts its SUM all-reduce (data parallel; the targets are [B,1]
     # vectors) as soon as its sweeps are queued, so the D/R/S exchanges overlap G's backward.
+    #
+    # Shared sweeps: the reference back-propagates through D(x_f) twice (tape of d_loss for D's weights, tape of
+    # g_final for the image gradient) and likewise through S(x_f).  Backprop is linear in the per-sample upstream
+    # scalar, so ONE sweep with upstream u_b produces both: sample b enters the weight gradients with factor
+    # gD_f[b]/u_b and the image gradient is rescaled by gG_d[b]/u_b (factors from the loss-head kernel, |.| <= 1).
+    g_step = (batch_idx + 1) % disc_iters == 0
+    share = share_backward and g_step
+    ones_b = torch.ones(B, device=dev)
     for m in (D, R, S):
         m.store.zero_grad()
     discriminator.trainable = True
-    if fuse:
+    dx_d = dx_s = None
+    if fuse and share:
+        dx_all = D.backward(ctx_D, torch.cat([shD[0], gD_r]), want_dx=True, want_dw=True, wscale=torch.cat([shD[1], ones_b]))
+        dx_d = ops.rowscale(dx_all[:B], shD[2])
+    elif fuse:
         D.backward(ctx_D, torch.cat([gD_f, gD_r]), want_dx=False, want_dw=True)
     else:
         D.backward(ctx_dr, gD_r, want_dx=False, want_dw=True)
-        D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
+        if share:
+            dx_d = ops.rowscale(D.backward(ctx_df, shD[0], want_dx=True, want_dw=True, wscale=shD[1]), shD[2])
+        else:
+            D.backward(ctx_df, gD_f, want_dx=False, want_dw=True)
     pending = [red.all_reduce_sum_async(D.store.grad)]
     recognizer.trainable = True
     ones = torch.ones_like(r_r)                                   # target r_real_logits: CTC on real only
@@ -212,29 +228,32 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     pending.append(red.all_reduce_sum_async(R.store.grad))
     style_promoter.trainable = True
     if fuse and fuse_style:
-        S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([gS_f, gS_my]), want_dx=False, want_dw=True)
-    elif fuse:
-        S.backward(S.slice_ctx(ctx_S, 0, B), gS_f, want_dx=False, want_dw=True)
-        S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
+        if share:
+            dxs_all = S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([shS[0], gS_my]), want_dx=True, want_dw=True,
+                                 wscale=torch.cat([shS[1], ones_b]))
+            dx_s = ops.rowscale(dxs_all[:B], shS[2])
+        else:
+            S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([gS_f, gS_my]), want_dx=False, want_dw=True)
     else:
         S.backward(ctx_smy, gS_my, want_dx=False, want_dw=True)
-        S.backward(ctx_sf, gS_f, want_dx=False, want_dw=True)
+        ctx_sf_ = S.slice_ctx(ctx_S, 0, B) if fuse else ctx_sf
+        if share:
+            dx_s = ops.rowscale(S.backward(ctx_sf_, shS[0], want_dx=True, want_dw=True, wscale=shS[1]), shS[2])
+        else:
+            S.backward(ctx_sf_, gS_f, want_dx=False, want_dw=True)
     pending.append(red.all_reduce_sum_async(S.store.grad))
-    g_step = (batch_idx + 1) % disc_iters == 0
     if g_step:
         recognizer.trainable = False
         discriminator.trainable = False
         style_promoter.trainable = False
         G.store.zero_grad()
-        if fuse:
-            dx = D.backward(D.slice_ctx(ctx_D, 0, B), gG_d, want_dx=True, want_dw=False)
-            ops.add(dx, S.backward(S.slice_ctx(ctx_S, 0, B), gG_s, want_dx=True, want_dw=False), out=dx)
-            ctx_rf_ = R.slice_ctx(ctx_R, 0, B) if fuse_r else ctx_rf
-            ops.add(dx, R.backward(ctx_rf_, gG_r, want_dx=True, want_dw=False), out=dx)
-        else:
-            dx = D.backward(ctx_df, gG_d, want_dx=True, want_dw=False)
-            ops.add(dx, S.backward(ctx_sf, gG_s, want_dx=True, want_dw=False), out=dx)
-            ops.add(dx, R.backward(ctx_rf, gG_r, want_dx=True, want_dw=False), out=dx)
+        if dx_d is None:
+            dx_d = D.backward(D.slice_ctx(ctx_D, 0, B) if fuse else ctx_df, gG_d, want_dx=True, want_dw=False)
+        if dx_s is None:
+            dx_s = S.backward(S.slice_ctx(ctx_S, 0, B) if fuse else ctx_sf, gG_s, want_dx=True, want_dw=False)
+        dx = ops.add(dx_d, dx_s, out=dx_d)
+        ctx_rf_ = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
+        ops.add(dx, R.backward(ctx_rf_, gG_r, want_dx=True, want_dw=False), out=dx)
         G.backward(ctx_g, dx)
 
     # ---- finish the gradient exchange, then the four updates ----

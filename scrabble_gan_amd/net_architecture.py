@@ -183,7 +183,7 @@ class _DownTrunk:
             out.append(((x[lo:hi], c1[lo:hi]), nlc))
         return out, net[lo:hi]
 
-    def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool):
+    def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool, wscale=None):
         ctxs, net = ctx
         d = ops.gap_bwd(dh, net, relu=True)
         for i in reversed(range(len(self.names))):
@@ -198,11 +198,12 @@ class _DownTrunk:
                 if isinstance(nlc, tuple) and len(nlc) == 2 and nlc[0] == "seg":
                     dn = torch.empty_like(d)
                     for lo, hi, cseg in nlc[1]:
-                        nn.nonlocal_bwd(cseg, d[lo:hi], sigma, dsig, dnlw, out=dn[lo:hi])
+                        nn.nonlocal_bwd(cseg, d[lo:hi], sigma, dsig, dnlw, out=dn[lo:hi],
+                                        wscale=None if wscale is None else wscale[lo:hi])
                     d = dn
                 else:
-                    d = nn.nonlocal_bwd(nlc, d, sigma, dsig, dnlw)
-            d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw)
+                    d = nn.nonlocal_bwd(nlc, d, sigma, dsig, dnlw, wscale=wscale)
+            d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw, wscale=wscale)
         return d
 
 
@@ -241,13 +242,16 @@ class DiscriminatorModel(_Model):
         tctx, h = ctx
         return self.trunk.slice_ctx(tctx, lo, hi), h[lo:hi]
 
-    def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool):
+    def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool, wscale=None):
+        """`wscale` [B]: the data-gradient chain runs with upstream `dlogits`, while sample b contributes to the weight
+        gradients with `wscale[b] * dlogits[b]` -- one sweep serving two targets (backprop is linear per sample)."""
         tctx, h = ctx
         dlogits = dlogits.reshape(-1, 1).contiguous()
         if want_dw:
-            ops.dense_bwd_weight(h, dlogits, self.store.g["dense.w"])
+            dl_w = dlogits if wscale is None else ops.rowscale(dlogits, wscale)
+            ops.dense_bwd_weight(h, dl_w, self.store.g["dense.w"])
         dh = ops.dense_bwd_input(dlogits, self.store.p["dense.w"])
-        return self.trunk.bwd(tctx, dh, self.store, want_dx, want_dw)
+        return self.trunk.bwd(tctx, dh, self.store, want_dx, want_dw, wscale=wscale)
 
     def __call__(self, inputs, training=False):
         x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs

@@ -148,17 +148,18 @@ def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
     return out, (x, c1)
 
 
-def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: bool, want_dw: bool):
+def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: bool, want_dw: bool, wscale=None):
+    """`wscale` [B] (optional) weights each sample's contribution to the WEIGHT gradients only (shared backward sweep)."""
     x, c1 = ctx
     p, g = S.p, S.g
     H, W = x.shape[1], x.shape[2]
     d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of both conv2's output and the 1x1 output
     if want_dw:
-        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"])
-        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"])
+        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1)
     if want_dw:
-        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"])
+        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
     if not want_dx:
         return None
     dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
@@ -214,11 +215,12 @@ def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor, out=None)
     return out, (x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o))
 
 
-def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Optional[Dict[str, torch.Tensor]] = None, out=None):
+def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Optional[Dict[str, torch.Tensor]] = None, out=None,
+                 wscale=None):
     x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o) = ctx
     B, H, W, C = x.shape
     Nq, Nk = H * W, (H // 2) * (W // 2)
-    ops.dot_accum(dout, oc, dsigma.view(1))
+    ops.dot_accum(dout if wscale is None else ops.rowscale(dout, wscale), oc, dsigma.view(1))
     d_oc = ops.scale(dout, sigma.view(1))
     d_o = ops.conv2d_bwd_data(d_oc, w_o, (H, W))
     dth, dph, dg = ops.attention_bwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2),
@@ -227,10 +229,10 @@ def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Opt
     dph_f = ops.maxpool_bwd(dph.view(B, H // 2, W // 2, C // 8), i_phi, 2, 2)
     dg_f = ops.maxpool_bwd(dg.view(B, H // 2, W // 2, C // 2), i_g, 2, 2)
     if dnlw is not None:     # 'persistent' mode: the 1x1 kernels are trainable
-        ops.conv2d_bwd_weight(o.view(B, H, W, C // 2), d_oc, dnlw["o"].view(1, 1, C // 2, C))
-        ops.conv2d_bwd_weight(x, dth, dnlw["theta"].view(1, 1, C, C // 8))
-        ops.conv2d_bwd_weight(x, dph_f, dnlw["phi"].view(1, 1, C, C // 8))
-        ops.conv2d_bwd_weight(x, dg_f, dnlw["g"].view(1, 1, C, C // 2))
+        ops.conv2d_bwd_weight(o.view(B, H, W, C // 2), d_oc, dnlw["o"].view(1, 1, C // 2, C), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dth, dnlw["theta"].view(1, 1, C, C // 8), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dph_f, dnlw["phi"].view(1, 1, C, C // 8), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dg_f, dnlw["g"].view(1, 1, C, C // 2), sample_scale=wscale)
     dx = ops.conv2d_bwd_data(dth, w_t, (H, W))
     ops.conv2d_bwd_data(dph_f, w_p, (H, W), out=dx, accum=True)
     ops.conv2d_bwd_data(dg_f, w_g, (H, W), out=dx, accum=True)

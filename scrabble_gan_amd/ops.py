@@ -122,14 +122,15 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     return out
 
 
-def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None):
-    """dw += weight-grad; db (optional, Cout > 1) += bias-grad in the same sweep over dy."""
-    _chk(x, dy, dw, db)
+def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale=None):
+    """dw += weight-grad; db (optional, Cout > 1) += bias-grad in the same sweep over dy; sample_scale [B] (optional)
+    weights each sample's contribution."""
+    _chk(x, dy, dw, db, sample_scale)
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
-        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
+        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
 
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
@@ -430,9 +431,10 @@ def loss_grads(d_r, d_f, s_my, s_f, s_r, r_f, mode: int, balance: bool, alpha: f
     B = d_r.numel()
     scalars = empty(16, like=d_r)
     outs = [empty(B, like=d_r) for _ in range(7)]
+    shD, shS = empty(3, B, like=d_r), empty(3, B, like=d_r)
     call("sg_loss_grads", _p(d_r), _p(d_f), _p(s_my), _p(s_f), _p(s_r), _p(r_f), B, mode, int(balance), float(alpha), sums.data_ptr(),
-         _p(scalars), *[_p(o) for o in outs], _stream())
-    return scalars, outs
+         _p(scalars), *[_p(o) for o in outs], _p(shD), _p(shS), _stream())
+    return scalars, outs + [shD, shS]
 
 
 # ---------------------------------------------------------------- optimizers / spectral norm

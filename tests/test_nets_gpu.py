@@ -251,7 +251,7 @@ def test_train_step(setup, dev, loss_name, balance, L_f):
             gr = ref_grads[net][k].double()
             mask = gr.abs() > max(1e-3 * gr.abs().max().item(), 1e-4 * net_max)
             if not (balance and net == "G"):       # (balanced mode: G's upstream is ill-conditioned here, see above)
-                assert ((got - ref).abs() * mask).max().item() <= 1e-5, "%s weight %s after Adam" % (net, k)   # 5 % of lr
+                assert ((got - ref).abs() * mask).max().item() <= 2e-5, "%s weight %s after Adam" % (net, k)   # 10 % of lr
             assert (got - ref).abs().max().item() <= 4.1e-4, "%s weight %s moved more than 2*lr" % (net, k)
     # trainable flags as left by the reference (:464-466)
     assert not D.trainable and not R.trainable and not S.trainable

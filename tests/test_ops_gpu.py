@@ -73,6 +73,14 @@ def test_conv2d_fwd_bwd(dev, gen, B, H, W, Cin, Cout, k, same):
     dbg = torch.zeros_like(bg)
     ops.bias_grad(dyg, dbg)
     close(dbg, b.grad, tol=5e-5, name="bias_grad")
+    if Cout > 1:      # per-sample weighting of the weight / bias gradients (shared backward sweeps)
+        s = rnd(gen, B)
+        w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        O.conv2d(torch.relu(x.detach()), w2, b2, padding="same" if same else "valid").backward(dy * s.view(-1, 1, 1, 1))
+        dws, dbs = torch.zeros_like(wg), torch.zeros_like(bg)
+        ops.conv2d_bwd_weight(xg, dyg, dws, same=same, relu_in=True, db=dbs, sample_scale=g32(s, dev))
+        close(dws, w2.grad, tol=5e-5, name="bwd_weight sample_scale")
+        close(dbs, b2.grad, tol=5e-5, name="bias_grad sample_scale")
 
 
 def test_conv2d_epilogues(dev, gen):
@@ -309,6 +317,11 @@ def test_loss_head(dev, gen, mode, balance):
     refs = [gD[0], gD[1], gS[0], gS[1], gG[0], gG[1] if gG[1] is not None else torch.zeros(B, 1), gG[2]]
     for i, (o, r) in enumerate(zip(outs, refs)):
         close(o, r.reshape(-1), tol=2e-4 if balance else 1e-5, name="upstream%d" % i)
+    # shared-sweep factors: u * w = d sum(d_loss)/d d_f (resp. s_loss/s_f), u * x = d sum(g_final)/d d_f (resp. s_f); |w|,|x| <= 1
+    for sh, a, c, nm in ((outs[7], refs[1], refs[4], "D"), (outs[8], refs[3], refs[5], "S")):
+        assert sh.shape == (3, B) and sh[1:].abs().max().item() <= 1.0 + 1e-6
+        close(sh[0] * sh[1], a.reshape(-1), tol=2e-4 if balance else 1e-5, name="shared w " + nm)
+        close(sh[0] * sh[2], c.reshape(-1), tol=2e-4 if balance else 1e-5, name="shared x " + nm)
 
 
 def test_adam_rmsprop_spectral(dev, gen):

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--L", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
+    ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
     args = ap.parse_args()
 
     from scrabble_gan_amd import data_utils as DU, dist as sdist, net_architecture as NA, net_loss, ops, optimizers
@@ -95,9 +97,12 @@ def main():
     images_d, my_d = torch.from_numpy(images).to(dev), torch.from_numpy(my_imgs).to(dev)
     labels_d, fake_d = torch.from_numpy(labels).to(dev), torch.from_numpy(fake).to(dev)
 
+    # sync="lazy": the 16 scalars of a step come back by an asynchronous copy and are read after the next step has
+    # been queued (as scrabble_gan_amd.data_utils.train does); every step's values are read and checked below.
     def step(i):
         return DU.train_step(0, i, args.steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
-                             net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake_d, verbose=False)
+                             net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake_d, verbose=False,
+                             sync=True if args.sync_every_step else "lazy")
 
     def fence():
         torch.cuda.synchronize()
@@ -111,16 +116,20 @@ def main():
     ops.PROFILER = timer
     fence()
     t0 = time.perf_counter()
+    outs = []
     for i in range(args.steps):
-        out = step(i)
+        outs.append(step(i))
+        if i:
+            tuple(outs[i - 1])                                    # read back step i-1 while step i runs
     fence()
+    tuple(outs[-1])
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
-    assert all(np.isfinite(float(v)) for v in out), out
+    assert all(np.isfinite(float(v)) for o in outs for v in o), outs
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -149,6 +158,12 @@ def main():
                                 "launches_per_step": ig["launches"] / args.steps, "ms_per_step": ig["ms"] / args.steps}
             line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / args.steps, 3),
                                    "launches_per_step": v["launches"] / args.steps} for k, v in ks.items()}
+        if timer is not None and args.shape_table:
+            with open(args.shape_table, "w") as f:
+                f.write("# per-shape MFMA conv launches inside train_step, per-GPU batch %d, %d steps (HIP events on the launch stream)\n" % (B // world, args.steps))
+                f.write("%-7s %-12s %5s %4s %4s %5s %5s %2s | %4s %9s %8s\n" % ("family", "kind", "B", "H", "W", "Cin", "Cout", "k", "n", "ms/step", "TFLOP/s"))
+                for fam, tag, n, ms_, tf in timer.by_shape():
+                    f.write("%-7s %-12s %5d %4d %4d %5d %5d %2d | %4d %9.3f %8.1f\n" % ((fam,) + tuple(tag) + (n // args.steps, ms_ / args.steps, tf)))
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

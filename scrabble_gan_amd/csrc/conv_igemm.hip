@@ -71,10 +71,21 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
 
   // ---- per-thread operand rows: everything that does not depend on the k-tile is hoisted, so the
-  //      loop body is one add + one bit test per load and can hide between the MFMAs ----
+  //      loop body is one add + one bit test per load and can hide between the MFMAs.
+  //      Operands are read with raw buffer loads (byte offsets in 32 bits, hardware range check): a lane that
+  //      must contribute zero (padding tap, row / channel past the edge) gets an out-of-range offset and the load
+  //      returns 0.0 without touching memory -- no select after the load, so the loaded registers are first
+  //      consumed by the LDS store three k-steps later and the VMEM latency hides under the MFMAs. ----
+  constexpr unsigned OOB = 0xFFFFFFE0u;
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+  const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
+  auto bload = [](decltype(rsrc_a) r, unsigned voff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return *reinterpret_cast<const float4*>(&v);
+  };
   const int kc = tid % KQ;
   const int row0 = tid / KQ;
-  int a_base[A_P];
+  unsigned a_base[A_P];       // byte offsets
   unsigned a_mask[A_P];
 #pragma unroll
   for (int i = 0; i < A_P; ++i) {
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
     const int yg = rem / p.Wg;
     const int xg = rem - yg * p.Wg;
     const int y = yg * p.a_sy, x = xg * p.a_sx;
-    a_base[i] = ((b * p.Ha + y) * p.Wa + x) * p.Ca + 4 * kc;
+    a_base[i] = 4u * (unsigned)(((b * p.Ha + y) * p.Wa + x) * p.Ca + 4 * kc);
     unsigned mk = 0;
     for (int t = 0; t < p.ntaps; ++t) {
       const int iy = y + p.taps[t].dy, ix = x + p.taps[t].dx;
@@ -94,70 +105,84 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
     }
     a_mask[i] = mk;
   }
-  int b_off[B_P];
+  unsigned b_off[B_P];        // byte offsets
   bool b_ok[B_P];
 #pragma unroll
   for (int i = 0; i < B_P; ++i) {
     if (B_NK) {
       const int n = n0 + row0 + i * (NT / KQ);
       b_ok[i] = n < p.N;
-      b_off[i] = n * p.ldw + 4 * kc;
+      b_off[i] = 4u * (unsigned)(n * p.ldw + 4 * kc);
     } else {
       const int k = tid / (BN / 4) + i * BKN_RPP;
       const int n = n0 + 4 * (tid % (BN / 4));
       b_ok[i] = n < p.N;
-      b_off[i] = k * p.ldw + n;
+      b_off[i] = 4u * (unsigned)(k * p.ldw + n);
     }
   }
 
   float4 a_reg[A_P];
   float4 b_reg[B_P];
   int lt = kt_begin / kchunks, lc0 = (kt_begin - (kt_begin / kchunks) * kchunks) * BK;   // (tap, channel offset) of the next k-tile to fetch
+  // tap constants of the next fetch (byte offsets), re-read from the argument block only when the cursor moves on to
+  // the next tap (a uniform, rarely taken branch)
+  int tap_off = 0, w_tap = 0;
+  auto set_tap = [&]() {
+    const int t = lt < p.ntaps ? lt : p.ntaps - 1;
+    tap_off = 4 * (p.taps[t].dy * p.Wa + p.taps[t].dx) * p.Ca;
+    w_tap = 4 * p.taps[t].w_off;
+  };
+  if (p.ntaps > 0) set_tap();
+  int wk = 4 * (B_NK ? lc0 : lc0 * p.ldw);              // byte offset of the k-tile's first weight row ([K,N]) / column ([N,K])
+  const int wk_step = 4 * (B_NK ? BK : BK * p.ldw);
+  const float relu_floor = relu_in ? 0.f : -__builtin_inff();   // ReLU on the operand without a branch in the loop
+  auto relu = [&](float v) {                                      // exactly one VALU op (no canonicalisation pass in front)
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(relu_floor));
+    return r;
+  };
 
-  // Branch-free loads: an out-of-range lane reads element 0 (always mapped) and the value is replaced by zero with
-  // selects, so the whole k-tile body stays ONE basic block and the scheduler can interleave VMEM / LDS / MFMA.
-  auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
   auto load_a = [&]() {
-    const int tap_off = (p.taps[lt].dy * p.Wa + p.taps[lt].dx) * p.Ca + lc0;
+    const unsigned toff = (unsigned)(tap_off + 4 * lc0);
     const bool cok = lc0 + 4 * kc < p.Ca;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       const bool ok = ((a_mask[i] >> lt) & 1u) && cok;
-      const int off = ok ? a_base[i] + tap_off : 0;
-      a_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(p.a + off));
+      a_reg[i] = bload(rsrc_a, ok ? a_base[i] + toff : OOB);
     }
   };
   auto load_b = [&]() {
-    const float* wt = p.w + p.taps[lt].w_off;
+    const unsigned woff = (unsigned)(w_tap + wk);
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
+      bool ok;
       if (B_NK) {
-        const bool ok = b_ok[i] && lc0 + 4 * kc < p.Ca;
-        const int off = ok ? b_off[i] + lc0 : 0;
-        b_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(wt + off));
+        ok = b_ok[i] && lc0 + 4 * kc < p.Ca;
       } else {
         const int k = tid / (BN / 4) + i * BKN_RPP;
-        const bool ok = b_ok[i] && lc0 + k < p.Ca;
-        const int off = ok ? b_off[i] + lc0 * p.ldw : 0;
-        b_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(wt + off));
+        ok = b_ok[i] && lc0 + k < p.Ca;
       }
+      b_reg[i] = bload(rsrc_w, ok ? b_off[i] + woff : OOB);
     }
     lc0 += BK;                       // advance the fetch cursor
-    if (lc0 >= p.Ca) { lc0 = 0; ++lt; }
+    wk += wk_step;
+    if (lc0 >= p.Ca) {               // uniform
+      lc0 = 0;
+      wk = 0;
+      ++lt;
+      set_tap();
+    }
   };
   auto store_a = [&](int buf) {
     float* as = As + buf * BK * LDA;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       const int r = row0 + i * (NT / KQ);
-      float4 v = a_reg[i];
-      if (relu_in) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      as[(4 * kc + 0) * LDA + r] = v.x;
-      as[(4 * kc + 1) * LDA + r] = v.y;
-      as[(4 * kc + 2) * LDA + r] = v.z;
-      as[(4 * kc + 3) * LDA + r] = v.w;
+      const float4 v = a_reg[i];
+      as[(4 * kc + 0) * LDA + r] = relu(v.x);
+      as[(4 * kc + 1) * LDA + r] = relu(v.y);
+      as[(4 * kc + 2) * LDA + r] = relu(v.z);
+      as[(4 * kc + 3) * LDA + r] = relu(v.w);
     }
   };
   auto store_b = [&](int buf) {
@@ -199,18 +224,28 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   }
   __syncthreads();
 
-  // One k-tile: the next tile's global loads are issued after the first MFMA groups and its LDS stores before the
-  // last ones, so address arithmetic, VMEM issue and LDS writes all sit in MFMA shadows (each 32x32x2 f32 MFMA
-  // leaves ~56 of its 64 cycles of vector issue free).  `more` is a compile-time tag: the last tile is peeled.
-  auto k_tile = [&](int buf, auto more_tag) {
-    constexpr bool more = decltype(more_tag)::value;
-    const float* as = As + buf * BK * LDA + khalf * LDA + a_col;
-    const float* bs = Bs + buf * BK * LDB + khalf * LDB + b_col;
-    float af[2][TM], bf[2][TN];     // fragment double buffer: k-step kk+1 is read from LDS under the MFMAs of kk
+  // Software pipeline over k-steps (one k-step = TM*TN MFMAs = 2 k): the LDS fragment reads of step s+1 are issued
+  // before the MFMAs of step s -- across k-tile boundaries too: the workgroup barrier sits one step before the end
+  // of a tile, so the last step already reads the first fragments of the next LDS buffer -- and sched_barriers keep
+  // the compiler from sinking them back next to their use.  The next tile's global loads go out in steps 0/1, its
+  // LDS stores in steps KS-5/KS-4, all in MFMA shadows (each 32x32x2 f32 MFMA leaves most of its 64 cycles of
+  // vector issue free).  `more` is a compile-time tag: the last tile is peeled.
+  static_assert(KS % 2 == 0 && KS >= 6, "fragment double buffer parity");
+  float af[2][TM], bf[2][TN];
+  {
+    const float* as = As + khalf * LDA + a_col;
+    const float* bs = Bs + khalf * LDB + b_col;
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = as[i * 32];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[0][j] = bs[j * 32];
+  }
+  auto k_tile = [&](int buf, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
+    const float* as = As + buf * BK * LDA + khalf * LDA + a_col;
+    const float* bs = Bs + buf * BK * LDB + khalf * LDB + b_col;
+    const float* as_n = As + (buf ^ 1) * BK * LDA + khalf * LDA + a_col;
+    const float* bs_n = Bs + (buf ^ 1) * BK * LDB + khalf * LDB + b_col;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -219,7 +254,13 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
         for (int i = 0; i < TM; ++i) af[nxt][i] = as[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[nxt][j] = bs[(kk + 1) * 2 * LDB + j * 32];
+      } else if constexpr (more) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nxt][i] = as_n[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = bs_n[j * 32];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,10 +270,11 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
         if (kk == 0) load_a();
         if (kk == 1) load_b();
         if (kk == KS - 5) store_a(buf ^ 1);
-        if (kk == KS - 3) store_b(buf ^ 1);
+        if (kk == KS - 4) store_b(buf ^ 1);
+        if (kk == KS - 2) __syncthreads();
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
   };
   for (int kt = 0; kt + 1 < KT; ++kt) k_tile(kt & 1, std::true_type{});
   if (KT > 0) k_tile((KT - 1) & 1, std::false_type{});
@@ -314,11 +356,18 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   return sg_launch_status();
 }
 
-int sg_launch_igemm(const SgIgemmArgs& a, bool b_nk, hipStream_t s) {
+int sg_launch_igemm(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
+  SgIgemmArgs a = a_in;
   if ((a.Ca & 3) || (a.ldw & 3) || (!b_nk && (a.N & 3))) return SG_ERR_ARG;
   if (a.ntaps < 0 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
-  if ((long)a.Bn * a.Ha * a.Wa * a.Ca >= (1L << 31) || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31))
-    return SG_ERR_ARG;  // 32-bit pixel indexing inside the kernel
+  // operands are addressed with 32-bit BYTE offsets (buffer loads), the output with 32-bit element indices
+  const long a_elems = (long)a.Bn * a.Ha * a.Wa * a.Ca;
+  long w_elems = 0;
+  for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
+  w_elems += (long)(b_nk ? a.N : a.Ca) * a.ldw;
+  if (a_elems >= (1L << 30) - 8 || w_elems >= (1L << 30) - 8 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_ARG;
+  a.a_bytes = (unsigned)(4 * a_elems);
+  a.w_bytes = (unsigned)(4 * w_elems);
   static const int bk_env = getenv("SG_IGEMM_BK") ? atoi(getenv("SG_IGEMM_BK")) : 16;   // tuning knobs
   static const int tile_env = getenv("SG_IGEMM_TILE") ? atoi(getenv("SG_IGEMM_TILE")) : 0;
   if (a.N > 64) {

@@ -26,6 +26,7 @@ struct SgIgemmArgs {
   int Hg, Wg, a_sy, a_sx;
   int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
   int ntaps, ldw, flags;
+  unsigned a_bytes, w_bytes;   // extents of a and w for the buffer-load range check (filled in by sg_launch_igemm)
   SgTap taps[SG_MAX_TAPS];
 };
 

@@ -111,7 +111,8 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     Extra keyword arguments (not in the reference): `fake_labels` overrides the host draw of :386-387
     (parity tests, data-parallel ranks that received their shard from rank 0); `nl` maps pass names
     ('G.style','G.up','D.fake','D.real','S.fake','S.style','S.real') to explicit NonLocalBlock
-    kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync; `fuse_passes=False`
+    kernels; `sync=False` returns the 16 scalars as a device tensor without a host sync and `sync="lazy"` a
+    StepScalars sequence that waits for its device-to-host copy on first access; `fuse_passes=False`
     keeps every reference call a separate pass even when the input widths match; `share_backward=False` runs the
     weight-gradient and image-gradient sweeps through D(x_f) / S(x_f) separately, as the reference's tapes do.
     """
@@ -269,11 +270,51 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
 
     if not sync:
         return scalars
-    s = scalars.tolist()                                         # the one host sync of the step
-    if verbose:
-        print('>%d, %d/%d, d=%.3f, d_real=%.3f, d_fake=%.3f, g_trad=%.3f, r_loss_fake=%.3f, g_loss=%.3f, r=%.3f, s=%.3f' % (
-            epoch_idx + 1, batch_idx + 1, batch_per_epoch, s[6], s[7], s[8], s[3], s[0], s[9], s[1], s[14]))
-    return (s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], 1, s[11], s[12], s[13], s[14], s[15])
+    out = StepScalars(scalars, (epoch_idx, batch_idx, batch_per_epoch) if verbose else None)
+    if sync == "lazy":
+        return out
+    return out.resolve()                                         # the one host sync of the step
+
+
+class StepScalars:
+    """The 16 scalars of data_utils.py:470-473 behind ONE asynchronous device-to-host copy.
+    `train_step(..., sync="lazy")` returns this sequence unresolved so the host can queue the next step while this
+    one still runs; the first access to a value (indexing, iteration) waits for the copy.  With the default
+    `sync=True` train_step resolves it and returns the plain 16-tuple, which is the reference's behaviour."""
+
+    def __init__(self, scalars, progress=None):
+        self._host = torch.empty(scalars.numel(), dtype=scalars.dtype, pin_memory=scalars.is_cuda)
+        self._host.copy_(scalars, non_blocking=True)
+        self._event = None
+        if scalars.is_cuda:
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(scalars.device))
+        self._values = None
+        self._progress = progress
+
+    def resolve(self):
+        if self._values is None:
+            if self._event is not None:
+                self._event.synchronize()
+            s = self._host.tolist()
+            self._values = (s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], 1, s[11], s[12], s[13], s[14], s[15])
+            if self._progress is not None:                      # the reference's per-step console line (:466-468)
+                e, b, n = self._progress
+                print('>%d, %d/%d, d=%.3f, d_real=%.3f, d_fake=%.3f, g_trad=%.3f, r_loss_fake=%.3f, g_loss=%.3f, r=%.3f, s=%.3f' % (
+                    e + 1, b + 1, n, s[6], s[7], s[8], s[3], s[0], s[9], s[1], s[14]))
+        return self._values
+
+    def __len__(self):
+        return 16
+
+    def __iter__(self):
+        return iter(self.resolve())
+
+    def __getitem__(self, i):
+        return self.resolve()[i]
+
+    def __repr__(self):
+        return repr(self.resolve())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -307,15 +348,24 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
         for epoch_idx in range(epochs):
             start = time.time()
             totals = [0.0] * 16
+            pending = None          # the previous step's scalars: read back after the next step is queued, so the
+                                    # device-to-host copy of the 16 values never drains the launch queue
+            def flush(res):
+                nonlocal totals
+                batch_summary.write(";".join(str(res[i]) for i in order) + "\n")
+                totals = [t + float(o) for t, o in zip(totals, res)]
             for batch_idx in range(batch_per_epoch):
                 image_batch, label_batch = next(dataset)
                 my_img_batch = random.choices(my_imgs, k=batch_size)
                 out = train_step(epoch_idx, batch_idx, batch_per_epoch, image_batch, label_batch, discriminator, recognizer,
                                  style_promoter, composite_gan, generator_optimizer, discriminator_optimizer,
                                  recognizer_optimizer, stylepromoter_optimizer, my_img_batch, batch_size, latent_dim, loss_fn,
-                                 disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path)
-                batch_summary.write(";".join(str(out[i]) for i in order) + "\n")
-                totals = [t + float(o) for t, o in zip(totals, out)]
+                                 disc_iters, apply_gradient_balance, random_words, bucket_size, gen_path, sync="lazy")
+                if pending is not None:
+                    flush(pending)
+                pending = out
+            if pending is not None:
+                flush(pending)
             epoch_summary.write(";".join(str(totals[i] / batch_per_epoch) for i in order) + "\n")
             print('Time for epoch {} is {} sec'.format(epoch_idx + 1, time.time() - start))
             generator.save_weights(os.path.join(generator_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))

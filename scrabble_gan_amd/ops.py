@@ -21,10 +21,11 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}
+        self.shapes = {}
 
     class _Region:
-        def __init__(self, timer, family, flops):
-            self.t, self.family, self.flops = timer, family, flops
+        def __init__(self, timer, family, flops, tag=None):
+            self.t, self.family, self.flops, self.tag = timer, family, flops, tag
 
         def __enter__(self):
             self.a = torch.cuda.Event(enable_timing=True)
@@ -34,9 +35,21 @@ class KernelTimer:
         def __exit__(self, *exc):
             self.b.record(torch.cuda.current_stream())
             self.t.records.setdefault(self.family, []).append((self.a, self.b, self.flops))
+            if self.tag is not None:
+                self.t.shapes.setdefault((self.family, self.tag), []).append((self.a, self.b, self.flops))
 
-    def region(self, family, flops):
-        return KernelTimer._Region(self, family, flops)
+    def region(self, family, flops, tag=None):
+        return KernelTimer._Region(self, family, flops, tag)
+
+    def by_shape(self):
+        """[(family, tag, launches, ms, tflops)] sorted by time, after a device synchronize."""
+        torch.cuda.synchronize()
+        rows = []
+        for (fam, tag), recs in self.shapes.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            rows.append((fam, tag, len(recs), ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0))
+        return sorted(rows, key=lambda r: -r[3])
 
     def summary(self):
         """{family: {launches, ms, tflops}} after a device synchronize."""
@@ -61,10 +74,10 @@ _NULL = _Null()
 PROFILER: Optional[KernelTimer] = None
 
 
-def _timed(family: str, flops: float, thin: bool):
+def _timed(family: str, flops: float, thin: bool, tag=None):
     if PROFILER is None:
         return _NULL
-    return PROFILER.region(family + ("_thin" if thin else ""), flops)
+    return PROFILER.region(family + ("_thin" if thin else ""), flops, tag)
 
 
 def _stream() -> int:
@@ -102,7 +115,8 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     Ho, Wo = (H, W) if same else (H - kh + 1, W - kw + 1)
     if out is None:
         out = empty(B, Ho, Wo, Cout, like=x)
-    with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+    with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
+                ("fwd", B, Ho, Wo, Cin, Cout, kh)):
         call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
              _flags(relu_in, accum, relu_out, tanh_out), _stream())
     return out
@@ -116,7 +130,8 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     assert dy.shape[3] == Cout
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+    with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
+                ("dgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
              _flags(accum=accum), _stream())
     return out
@@ -129,7 +144,8 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
-    with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1):
+    with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
+                ("wgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
 
 
@@ -141,7 +157,7 @@ def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, a
     sh, sw = stride
     if out is None:
         out = empty(B, sh * H, sw * W, Cout, like=x)
-    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_fwd", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
              _flags(accum=accum), _stream())
     return out
@@ -155,7 +171,7 @@ def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=F
     H, W = Hs // sh, Ws // sw
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_dgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
              _flags(accum=accum), _stream())
     return out
@@ -167,7 +183,7 @@ def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
     kh, kw, Cout, wc = dw.shape
     assert wc == Cin
     sh, sw = stride
-    with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False):
+    with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_wgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_transpose_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, 0, _stream())
 
 

@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // IDENT: both operands live on the base grid with unit sampling stride (every stride-1 Conv2D weight-grad): their
 // addresses are linear in the pixel index, so the k-loop needs one add per load; only the tap validity of P still
 // follows a (y, x) cursor.  The general form (strided sampling: transposed convolutions) keeps full cursors.
-template <int BC, int BN, int WM, int WN, int BK, int OCC, bool IDENT>
+template <int BC, int BN, int WM, int WN, int BK, int OCC, bool IDENT, bool QSCALE>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgradArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
@@ -43,10 +43,22 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
 
   float4 p_reg[P_P], q_reg[Q_P];
+  float q_sc[Q_P];
   const int pc = c0 + 4 * (tid % (BC / 4));
   const int qn = n0 + 4 * (tid % (BN / 4));
   const bool p_cok = pc < p.Cp, q_cok = qn < p.Cq;
   constexpr int KS = BK / 2;
+
+  // Operands come in through raw buffer loads (32-bit byte offsets, hardware range check): a lane that must
+  // contribute zero (padding tap, pixel past the chunk, channel past the edge) gets an out-of-range offset and
+  // reads 0.0 -- no select after the load, so the registers are first touched by the LDS store three k-steps later.
+  constexpr unsigned OOB = 0xFFFFFFE0u;
+  const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.p), 0, (int)p.p_bytes, 0x00020000);
+  const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.q), 0, (int)p.q_bytes, 0x00020000);
+  auto bload = [](decltype(rsrc_p) r, unsigned voff) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return *reinterpret_cast<const float4*>(&v);
+  };
 
   // Per-slot pixel cursors (b, yg, xg), decoded once and advanced by BK pixels per k-tile with
   // compare/subtract wraps: no integer division inside the loop.
@@ -74,37 +86,46 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     yy -= cy * p.Hg;
     bb += adv_b + cy;
   };
-  auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+  const float relu_floor = relu_in ? 0.f : -__builtin_inff();
+  auto relu = [&](float v) {                                      // exactly one VALU op
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(relu_floor));
+    return r;
+  };
+  // IDENT: both addresses are linear in the pixel index -> per-slot byte offsets advanced by one add per k-tile
+  unsigned p_lin[P_P], q_lin[Q_P];
+#pragma unroll
+  for (int i = 0; i < P_P; ++i)
+    p_lin[i] = 4u * (unsigned)((m_begin + tid / (BC / 4) + i * P_RPP + dy * p.Wp + dx) * p.Cp + pc);
+#pragma unroll
+  for (int i = 0; i < Q_P; ++i) q_lin[i] = 4u * (unsigned)((m_begin + tid / (BN / 4) + i * Q_RPP) * p.Cq + qn);
+  const unsigned p_step = 4u * BK * p.Cp, q_step = 4u * BK * p.Cq;
 
-  // branch-free loads (an out-of-range lane reads element 0 and is zeroed by selects): one basic block per k-tile
   auto load_p = [&]() {
 #pragma unroll
     for (int i = 0; i < P_P; ++i) {
       const int m = m_next + tid / (BC / 4) + i * P_RPP;
-      const int iy = py[i] * p.p_sy + dy, ix = px[i] * p.p_sx + dx;
-      const bool ok = m < m_end && p_cok && iy >= 0 && iy < p.Hp && ix >= 0 && ix < p.Wp;
-      const int off = !ok ? 0 : IDENT ? (m + dy * p.Wp + dx) * p.Cp + pc : ((pb[i] * p.Hp + iy) * p.Wp + ix) * p.Cp + pc;
-      p_reg[i] = sel4(ok, *reinterpret_cast<const float4*>(p.p + off));
+      const int iy = (IDENT ? py[i] : py[i] * p.p_sy) + dy, ix = (IDENT ? px[i] : px[i] * p.p_sx) + dx;
+      // (bitwise &: one straight-line compare chain, no short-circuit branches in the loop)
+      const bool ok = (m < m_end) & p_cok & ((unsigned)iy < (unsigned)p.Hp) & ((unsigned)ix < (unsigned)p.Wp);
+      const unsigned off = IDENT ? p_lin[i] : 4u * (unsigned)(((pb[i] * p.Hp + iy) * p.Wp + ix) * p.Cp + pc);
+      p_reg[i] = bload(rsrc_p, ok ? off : OOB);
+      p_lin[i] += p_step;
       advance(pb[i], py[i], px[i]);
     }
   };
   const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;     // one (tap, c-tile) column of workgroups sums dy
-  const bool qscaled = p.qscale != nullptr;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_q = [&]() {
 #pragma unroll
     for (int i = 0; i < Q_P; ++i) {
       const int m = m_next + tid / (BN / 4) + i * Q_RPP;
-      const bool ok = m < m_end && q_cok;
-      const int off = !ok ? 0 : IDENT ? m * p.Cq + qn : ((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn;
-      float4 v = sel4(ok, *reinterpret_cast<const float4*>(p.q + off));
-      if (qscaled) {                                   // block-uniform
-        const float sc = p.qscale[ok ? qb[i] : 0];
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-      }
-      q_reg[i] = v;
-      if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-      if (!IDENT || qscaled) advance(qb[i], qy[i], qx[i]);
+      const bool ok = (m < m_end) & q_cok;
+      const unsigned off = IDENT ? q_lin[i] : 4u * (unsigned)(((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn);
+      q_reg[i] = bload(rsrc_q, ok ? off : OOB);
+      q_lin[i] += q_step;
+      if (QSCALE) q_sc[i] = p.qscale[ok ? qb[i] : 0];             // the per-sample factor is applied at the LDS store
+      if (!IDENT || QSCALE) advance(qb[i], qy[i], qx[i]);
     }
     m_next += BK;
   };
@@ -113,15 +134,19 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
 #pragma unroll
     for (int i = 0; i < P_P; ++i) {
       float4 v = p_reg[i];
-      if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
       *reinterpret_cast<float4*>(ps + (tid / (BC / 4) + i * P_RPP) * BC + 4 * (tid % (BC / 4))) = v;
     }
   };
   auto store_q = [&](int buf) {
     float* qs = Qs + buf * BK * BN;
 #pragma unroll
-    for (int i = 0; i < Q_P; ++i)
-      *reinterpret_cast<float4*>(qs + (tid / (BN / 4) + i * Q_RPP) * BN + 4 * (tid % (BN / 4))) = q_reg[i];
+    for (int i = 0; i < Q_P; ++i) {
+      float4 v = q_reg[i];
+      if (QSCALE) { v.x *= q_sc[i]; v.y *= q_sc[i]; v.z *= q_sc[i]; v.w *= q_sc[i]; }
+      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;    // column sums of Q (used by the do_bias workgroups)
+      *reinterpret_cast<float4*>(qs + (tid / (BN / 4) + i * Q_RPP) * BN + 4 * (tid % (BN / 4))) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -143,15 +168,25 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     store_q(0);
   }
   __syncthreads();
-  auto k_tile = [&](int buf, auto more_tag) {
-    constexpr bool more = decltype(more_tag)::value;       // the last tile (nothing left to prefetch) is peeled
-    const float* ps = Ps + buf * BK * BC + khalf * BC + a_col;
-    const float* qs = Qs + buf * BK * BN + khalf * BN + b_col;
-    float af[2][TM], bf[2][TN];
+  // Same software pipeline as sg_igemm_kernel: fragment reads of k-step s+1 issued before the MFMAs of step s, across
+  // k-tile boundaries (workgroup barrier one step before the end of a tile), pinned with sched_barriers; next tile's
+  // buffer loads in steps 0/1, its LDS stores in steps KS-5/KS-4.
+  static_assert(KS % 2 == 0 && KS >= 6, "fragment double buffer parity");
+  float af[2][TM], bf[2][TN];
+  {
+    const float* ps = Ps + khalf * BC + a_col;
+    const float* qs = Qs + khalf * BN + b_col;
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = ps[i * 32];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[0][j] = qs[j * 32];
+  }
+  auto k_tile = [&](int buf, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;       // the last tile (nothing left to prefetch) is peeled
+    const float* ps = Ps + buf * BK * BC + khalf * BC + a_col;
+    const float* qs = Qs + buf * BK * BN + khalf * BN + b_col;
+    const float* ps_n = Ps + (buf ^ 1) * BK * BC + khalf * BC + a_col;
+    const float* qs_n = Qs + (buf ^ 1) * BK * BN + khalf * BN + b_col;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -160,27 +195,34 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
         for (int i = 0; i < TM; ++i) af[nxt][i] = ps[(kk + 1) * 2 * BC + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[nxt][j] = qs[(kk + 1) * 2 * BN + j * 32];
+      } else if constexpr (more) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[nxt][i] = ps_n[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = qs_n[j * 32];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-      // next k-tile: global loads right after the first MFMA groups, LDS stores before the last ones
       if constexpr (more) {
         if (kk == 0) load_p();
         if (kk == 1) load_q();
         if (kk == KS - 5) store_p(buf ^ 1);
-        if (kk == KS - 3) store_q(buf ^ 1);
+        if (kk == KS - 4) store_q(buf ^ 1);
+        if (kk == KS - 2) __syncthreads();
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
   };
   for (int kt = 0; kt + 1 < KT; ++kt) k_tile(kt & 1, std::true_type{});
   if (KT > 0) k_tile((KT - 1) & 1, std::false_type{});
 
   if (do_bias) {      // (block-uniform) reduce the per-thread column sums over the Q_RPP row lanes, one atomic per column
     float4* red = reinterpret_cast<float4*>(smem);
+    __syncthreads();                 // every wave is done with the operand tiles
     red[tid] = bsum;
     __syncthreads();
     if (tid < BN / 4) {
@@ -228,24 +270,28 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;
   a.mchunk = (int)mchunk;
-  if (wgrad_ident(a))
-    hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true>), dim3((unsigned)(combos * nchunks)), dim3(WM * WN * 64), 0, s, a);
-  else
-    hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false>), dim3((unsigned)(combos * nchunks)), dim3(WM * WN * 64), 0, s, a);
+  const dim3 grid((unsigned)(combos * nchunks)), block(WM * WN * 64);
+  const bool ident = wgrad_ident(a), qs = a.qscale != nullptr;
+  if (ident && qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, true>), grid, block, 0, s, a);
+  else if (ident) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, false>), grid, block, 0, s, a);
+  else if (qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, false>), grid, block, 0, s, a);
   return sg_launch_status();
 }
 
-int sg_launch_wgrad(const SgWgradArgs& a, hipStream_t s) {
+int sg_launch_wgrad(const SgWgradArgs& a_in, hipStream_t s) {
+  SgWgradArgs a = a_in;
   if ((a.Cp & 3) || (a.Cq & 3) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
-  if ((long)a.Bn * a.Hp * a.Wp * a.Cp >= (1L << 31) || (long)a.Bn * a.Hq * a.Wq * a.Cq >= (1L << 31))
-    return SG_ERR_ARG;
+  const long p_elems = (long)a.Bn * a.Hp * a.Wp * a.Cp, q_elems = (long)a.Bn * a.Hq * a.Wq * a.Cq;
+  if (p_elems >= (1L << 30) - 8 || q_elems >= (1L << 30) - 8) return SG_ERR_ARG;   // 32-bit byte offsets (buffer loads)
+  a.p_bytes = (unsigned)(4 * p_elems);
+  a.q_bytes = (unsigned)(4 * q_elems);
   const bool c_small = a.Cp <= 64, n_small = a.Cq <= 64;
-  static const int bk_env = getenv("SG_WGRAD_BK") ? atoi(getenv("SG_WGRAD_BK")) : 16;   // tuning knob
-  if (!c_small && !n_small)
-    return bk_env == 16 ? launch_wgrad_cfg<128, 128, 2, 2, 16, 3>(a, s) : launch_wgrad_cfg<128, 128, 2, 2>(a, s);
-  if (!c_small) return bk_env == 16 ? launch_wgrad_cfg<128, 64, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<128, 64, 2, 2>(a, s);
-  if (!n_small) return bk_env == 16 ? launch_wgrad_cfg<64, 128, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<64, 128, 2, 2>(a, s);
-  return bk_env == 16 ? launch_wgrad_cfg<64, 64, 2, 2, 16, 4>(a, s) : launch_wgrad_cfg<64, 64, 2, 2>(a, s);
+  // (BK = 32 k-tiles at 2 workgroups per CU were measured earlier and dropped: 16 at 3-4 per CU is faster everywhere)
+  if (!c_small && !n_small) return launch_wgrad_cfg<128, 128, 2, 2, 16, 3>(a, s);
+  if (!c_small) return launch_wgrad_cfg<128, 64, 2, 2, 16, 4>(a, s);
+  if (!n_small) return launch_wgrad_cfg<64, 128, 2, 2, 16, 4>(a, s);
+  return launch_wgrad_cfg<64, 64, 2, 2, 16, 4>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ struct SgWgradArgs {
   int Hg, Wg;
   int ntaps, flags;    // SG_RELU_IN applies to P
   int mchunk;          // base pixels per block (multiple of 32)
+  unsigned p_bytes, q_bytes;   // extents of p and q for the buffer-load range check (filled in by sg_launch_wgrad)
   SgTap taps[SG_MAX_TAPS];
 };
 

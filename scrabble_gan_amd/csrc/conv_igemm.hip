@@ -56,16 +56,29 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   const int M = p.Bn * p.Hg * p.Wg;
   const int HW = p.Hg * p.Wg;
   const int n_tiles = (p.N + BN - 1) / BN;
-  const int wg = sg_xcd_remap(blockIdx.x, gridDim.x);
+  // Work decomposition: the first `full_tiles` workgroups own one output tile each (whole reduction, plain stores).
+  // The tiles of the last, partly filled round of resident workgroups -- or all tiles when the grid cannot fill the
+  // chip at all (small per-GPU batches) -- are cut `tail_split` ways along the reduction instead, so that the tail
+  // of the launch still occupies every CU: such a workgroup reduces k-tiles [kt_begin, kt_begin + KT) and adds its
+  // partial tile to the (pre-zeroed or accumulated-into) output with float atomics; every fused epilogue term used
+  // with it (bias, 0/1 mask, accumulate) is linear in the partial sums.  Tail units are dispatched last.
+  int wg, split, nsplit;
+  if ((int)blockIdx.x < p.full_tiles) {
+    wg = sg_xcd_remap(blockIdx.x, p.full_tiles);
+    split = 0;
+    nsplit = 1;
+  } else {
+    const int tail_tiles = p.n_tiles_total - p.full_tiles;
+    const int u = sg_xcd_remap(blockIdx.x - p.full_tiles, tail_tiles * p.tail_split);
+    nsplit = p.tail_split;
+    split = u / tail_tiles;            // units of one k-range are neighbours: they share operand rows in L2
+    wg = p.full_tiles + (u - split * tail_tiles);
+  }
   const int m0 = (wg / n_tiles) * BM;
   const int n0 = (wg % n_tiles) * BN;
 
   const int kchunks = (p.Ca + BK - 1) / BK;
   const int KT_all = p.ntaps * kchunks;
-  // split-K (gridDim.y > 1): this workgroup reduces k-tiles [kt_begin, kt_begin + KT) and adds its partial
-  // tile to the (pre-zeroed or accumulated-into) output with float atomics; all fused epilogue terms
-  // used with it (bias, 0/1 mask, accumulate) are linear in the partial sums
-  const int nsplit = gridDim.y, split = blockIdx.y;
   const int kt_begin = (int)(((long)KT_all * split) / nsplit);
   const int KT = (int)(((long)KT_all * (split + 1)) / nsplit) - kt_begin;
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
@@ -329,26 +342,61 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   SgIgemmArgs a = a_in;
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG_IDENT_OUT;
   const long M = (long)a.Bn * a.Hg * a.Wg;
-  const int grid = sg_cdiv(M, BM) * sg_cdiv(a.N, BN);
-  if (grid <= 0) return SG_OK;
-  // split-K when the tile grid cannot fill the chip (small per-GPU batches under data parallelism):
-  // aim at >= ~3 workgroups per CU, keep >= 16 k-tiles per split; not with a non-linear epilogue
+  const int n_tiles = sg_cdiv(a.N, BN);
+  const int tiles = sg_cdiv(M, BM) * n_tiles;
+  if (tiles <= 0) return SG_OK;
   static const int split_env0 = getenv("SG_IGEMM_SPLITK") ? atoi(getenv("SG_IGEMM_SPLITK")) : 0;
-  const int split_env = g_split_override >= 0 ? g_split_override : split_env0;
+  const int split_env = g_split_override >= 0 ? g_split_override : split_env0;   // 1 = never split, n > 1 = cut every tile n ways
   const int KT_all = a.ntaps * sg_cdiv(a.Ca, BK);
-  int nsplit = 1;
-  if (!(a.flags & SG_RELU_OUT) && grid < 768 && KT_all >= 32) {
-    nsplit = (1024 + grid - 1) / grid;
-    if (nsplit > KT_all / 16) nsplit = KT_all / 16;
-    if (nsplit > 16) nsplit = 16;
-    if (nsplit < 1) nsplit = 1;
+  // partial sums need a linear epilogue and an output that is zero (or holds the accumulate operand) beforehand;
+  // strided output placement (transposed convolution classes) is only split when it accumulates
+  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG_IDENT_OUT));
+  // Balance model: workgroups are handed to the 256 CUs round-robin and share a CU's matrix pipes, so a launch of T
+  // equal tiles takes ceil(T / 256) tile-times.  The tiles beyond the last multiple of 256 (all of them when T < 256)
+  // are cut `sp` ways along the reduction, sp chosen to minimise ceil(tail * sp / 256) / sp, with a small charge per
+  // cut for the atomic epilogue and the extra prologues and a charge when a CU would hold fewer than 3 workgroups.
+  constexpr int CUS = 256;
+  int full = tiles, nsplit = 1;
+  if (can_split && split_env != 1 && KT_all >= 16) {
+    const int rem = tiles % CUS;
+    if (split_env > 1) {
+      full = 0;
+      nsplit = split_env < KT_all ? split_env : 1;
+    } else if (rem > 0) {
+      // (with fewer than 3 whole tiles per CU every tile is cut: a CU then still holds 3 workgroups at a time)
+      const int full_c = tiles < 3 * CUS ? 0 : (tiles - rem) / n_tiles * n_tiles;   // the tail starts on an m-tile boundary: its rows are contiguous
+      const int tail = tiles - full_c;
+      auto cost = [&](int sp) {
+        const int units = tail * sp;
+        const int per_cu = (units + CUS - 1) / CUS;
+        const int resident = full_c > 0 ? OCC : (per_cu < OCC ? per_cu : OCC);
+        const double eff = resident >= 3 ? 1.0 : (resident == 2 ? 0.9 : 0.7);
+        return (double)per_cu / sp * (1.0 + 0.01 * (sp - 1)) / eff;
+      };
+      int best = 1;
+      double best_cost = cost(1);
+      const int sp_max = KT_all / 8 < 16 ? KT_all / 8 : 16;
+      for (int sp = 2; sp <= sp_max; ++sp) {
+        const double c = cost(sp);
+        if (c < 0.97 * best_cost) {
+          best = sp;
+          best_cost = c;
+        }
+      }
+      if (best > 1) {
+        full = full_c;
+        nsplit = best;
+      }
+    }
   }
-  if (split_env > 0 && !(a.flags & SG_RELU_OUT)) nsplit = split_env < KT_all ? split_env : 1;
-  if (nsplit > 1 && !(a.flags & SG_ACCUM)) {
-    if (!(a.flags & SG_IDENT_OUT)) nsplit = 1;   // strided output placement (transposed conv): keep the single pass
-    else if (hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)M * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  if (nsplit > 1 && !(a.flags & SG_ACCUM)) {         // zero the rows the partial tiles add into (IDENT_OUT: one contiguous range)
+    const size_t row0 = (size_t)(full / n_tiles) * BM;
+    if (hipMemsetAsync(a.out + row0 * a.N, 0, sizeof(float) * ((size_t)M - row0) * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
   }
-  const dim3 g3(grid, nsplit);
+  a.full_tiles = full;
+  a.tail_split = nsplit;
+  a.n_tiles_total = tiles;
+  const dim3 g3(full + (tiles - full) * nsplit);
   if (b_nk)
     hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   else
@@ -368,23 +416,25 @@ int sg_launch_igemm(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   if (a_elems >= (1L << 30) - 8 || w_elems >= (1L << 30) - 8 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_ARG;
   a.a_bytes = (unsigned)(4 * a_elems);
   a.w_bytes = (unsigned)(4 * w_elems);
-  static const int bk_env = getenv("SG_IGEMM_BK") ? atoi(getenv("SG_IGEMM_BK")) : 16;   // tuning knobs
-  static const int tile_env = getenv("SG_IGEMM_TILE") ? atoi(getenv("SG_IGEMM_TILE")) : 0;
+  static const int tile_env = getenv("SG_IGEMM_TILE") ? atoi(getenv("SG_IGEMM_TILE")) : 0;   // tuning knob
+  // (BK = 32 k-tiles at 2 workgroups per CU were measured earlier and dropped: 16 at 3-4 per CU is faster everywhere)
   if (a.N > 64) {
-    // tile choice: 128x128 unless its grid leaves the 256 CUs badly balanced (few tiles per CU with a
-    // large fractional remainder); 128x64 then doubles the tile count at a small efficiency cost
+    // 128x128 tiles; 128x64 only where the reduction cannot be split (non-linear epilogue, strided placement) and the
+    // wider tile would leave the 256 CUs badly balanced (few tiles per CU with a large fractional remainder)
     const long M = (long)a.Bn * a.Hg * a.Wg;
     const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(a.N, 128), t64 = (long)sg_cdiv(M, 128) * sg_cdiv(a.N, 64);
     const double e128 = (double)t128 / (((t128 + 255) / 256) * 256.0);
     const double e64 = 0.93 * (double)t64 / (((t64 + 255) / 256) * 256.0);
-    const bool narrow = tile_env == 64 || (tile_env == 0 && t128 < 2048 && e64 > e128);
-    if (narrow) return bk_env == 16 ? launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s) : launch_cfg<128, 64, 2, 2>(a, b_nk, s);
-    return bk_env == 16 ? launch_cfg<128, 128, 2, 2, 16, 3>(a, b_nk, s) : launch_cfg<128, 128, 2, 2>(a, b_nk, s);
+    const bool ident = a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg;
+    const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || ident);
+    const bool narrow = tile_env == 64 || (tile_env == 0 && !can_split && t128 < 2048 && e64 > e128);
+    if (narrow) return launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s);
+    return launch_cfg<128, 128, 2, 2, 16, 3>(a, b_nk, s);
   }
   if (a.N > 32) {
     // (measured and dropped: 256x64 tiles for N <= 64, 2-wave workgroups with 128x64 wave tiles, s_setprio around the
     //  MFMA clusters, staggered workgroup starts -- none beat this configuration)
-    return bk_env == 16 ? launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s) : launch_cfg<128, 64, 2, 2>(a, b_nk, s);
+    return launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s);
   }
   return launch_cfg<128, 32, 4, 1>(a, b_nk, s);
 }

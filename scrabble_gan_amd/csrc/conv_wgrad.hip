@@ -262,10 +262,20 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int combos = a.ntaps * sg_cdiv(a.Cp, BC) * sg_cdiv(a.Cq, BN);
   if (combos <= 0 || M <= 0) return SG_OK;
-  long nchunks = (2048 + combos - 1) / combos;           // ~2048 workgroups: 8 per CU
-  const long max_chunks = (M + 255) / 256;               // at least 8 k-tiles per workgroup
-  if (nchunks > max_chunks) nchunks = max_chunks;
-  if (nchunks < 1) nchunks = 1;
+  // ~1500-3000 workgroups (6-12 per CU), the count picked so that combos * nchunks fills whole rounds of the 256 CUs
+  // (a launch of W equal workgroups takes ceil(W / 256) workgroup-times); at least 8 k-tiles per workgroup
+  const long max_chunks = (M + 255) / 256;
+  long nchunks = 1;
+  double best = 1e30;
+  for (long c = (1536 + combos - 1) / combos; c <= (3072 + combos - 1) / combos; ++c) {
+    const long cc = c < 1 ? 1 : (c > max_chunks ? max_chunks : c);
+    const long W = combos * cc;
+    const double loss = (double)((W + 255) / 256) * 256.0 / (double)W * (1.0 + 0.002 * cc);   // + epilogue cost per chunk
+    if (loss < best) {
+      best = loss;
+      nchunks = cc;
+    }
+  }
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;

@@ -27,6 +27,7 @@ struct SgIgemmArgs {
   int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
   int ntaps, ldw, flags;
   unsigned a_bytes, w_bytes;   // extents of a and w for the buffer-load range check (filled in by sg_launch_igemm)
+  int full_tiles, tail_split, n_tiles_total;   // work decomposition (filled in by the launcher): see sg_igemm_kernel
   SgTap taps[SG_MAX_TAPS];
 };
 

@@ -22,10 +22,11 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
         self.shapes = {}
+        self.nbytes = {}        # algorithmic bytes (operands read once + result written once) per family
 
     class _Region:
-        def __init__(self, timer, family, flops, tag=None):
-            self.t, self.family, self.flops, self.tag = timer, family, flops, tag
+        def __init__(self, timer, family, flops, tag=None, nbytes=0.0):
+            self.t, self.family, self.flops, self.tag, self.nbytes = timer, family, flops, tag, nbytes
 
         def __enter__(self):
             self.a = torch.cuda.Event(enable_timing=True)
@@ -35,11 +36,12 @@ class KernelTimer:
         def __exit__(self, *exc):
             self.b.record(torch.cuda.current_stream())
             self.t.records.setdefault(self.family, []).append((self.a, self.b, self.flops))
+            self.t.nbytes[self.family] = self.t.nbytes.get(self.family, 0.0) + self.nbytes
             if self.tag is not None:
                 self.t.shapes.setdefault((self.family, self.tag), []).append((self.a, self.b, self.flops))
 
-    def region(self, family, flops, tag=None):
-        return KernelTimer._Region(self, family, flops, tag)
+    def region(self, family, flops, tag=None, nbytes=0.0):
+        return KernelTimer._Region(self, family, flops, tag, nbytes)
 
     def by_shape(self):
         """[(family, tag, launches, ms, tflops)] sorted by time, after a device synchronize."""
@@ -58,7 +60,8 @@ class KernelTimer:
         for fam, recs in self.records.items():
             ms = sum(a.elapsed_time(b) for a, b, _ in recs)
             fl = sum(f for _, _, f in recs)
-            out[fam] = {"launches": len(recs), "ms": ms, "flops": fl, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+            out[fam] = {"launches": len(recs), "ms": ms, "flops": fl, "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                        "bytes": self.nbytes.get(fam, 0.0)}
         return out
 
 
@@ -74,10 +77,10 @@ _NULL = _Null()
 PROFILER: Optional[KernelTimer] = None
 
 
-def _timed(family: str, flops: float, thin: bool, tag=None):
+def _timed(family: str, flops: float, thin: bool, tag=None, tensors=()):
     if PROFILER is None:
         return _NULL
-    return PROFILER.region(family + ("_thin" if thin else ""), flops, tag)
+    return PROFILER.region(family + ("_thin" if thin else ""), flops, tag, 4.0 * sum(t.numel() for t in tensors if t is not None))
 
 
 def _stream() -> int:
@@ -116,7 +119,7 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     if out is None:
         out = empty(B, Ho, Wo, Cout, like=x)
     with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
-                ("fwd", B, Ho, Wo, Cin, Cout, kh)):
+                ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
         call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
              _flags(relu_in, accum, relu_out, tanh_out), _stream())
     return out
@@ -131,7 +134,7 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
     with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
-                ("dgrad", B, H, W, Cin, Cout, kh)):
+                ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
         call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
              _flags(accum=accum), _stream())
     return out
@@ -157,7 +160,7 @@ def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, a
     sh, sw = stride
     if out is None:
         out = empty(B, sh * H, sw * W, Cout, like=x)
-    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_fwd", B, H, W, Cin, Cout, kh)):
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_fwd", B, H, W, Cin, Cout, kh), (x, w, out)):
         call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
              _flags(accum=accum), _stream())
     return out
@@ -171,7 +174,7 @@ def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=F
     H, W = Hs // sh, Ws // sw
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_dgrad", B, H, W, Cin, Cout, kh)):
+    with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
         call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
              _flags(accum=accum), _stream())
     return out

@@ -42,13 +42,22 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* x, float*
   }
 }
 
-// stage 2: sums[0][c], sums[1][c] (fp64) = sum over blocks
+// stage 2: sums[0][c], sums[1][c] (fp64) = sum over blocks.  16 columns x 16 block-lanes per workgroup: each thread
+// adds every 16th partial (independent loads, short chain), then an LDS tree over the lanes in fp64.
 __global__ __launch_bounds__(256) void k_bn_stats_combine(const float* partial, double* sums, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * 2 * C + c];
-  sums[c] = s;
+  if (c < 2 * C)
+    for (int b = bl; b < nblk; b += 16) s += (double)partial[(size_t)b * 2 * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 8; st > 0; st >>= 1) {
+    if (bl < st) red[threadIdx.x] += red[threadIdx.x + st * 16];
+    __syncthreads();
+  }
+  if (bl == 0 && c < 2 * C) sums[c] = red[threadIdx.x];
 }
 
 // stage 3: mean/var (biased) from (possibly all-reduced) fp64 sums and the global row count
@@ -191,14 +200,21 @@ __global__ void k_bn_update_moving(float* mm, float* mv, const float* mean, cons
 
 static inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= 256; }
 
-extern "C" long sg_bn_stats_workspace_floats(long M, int C) { return (long)sg_cdiv(M, 2048) * 2 * C; }
+// rows per workgroup of the statistics sweep: ~512 workgroups (the second stage walks them serially per channel),
+// 32..2048 rows each -- small per-GPU batches must still spread over the chip
+static inline int bn_stats_rpb(long M) {
+  long r = (M + 511) / 512;
+  return (int)(r < 32 ? 32 : (r > 2048 ? 2048 : r));
+}
+
+extern "C" long sg_bn_stats_workspace_floats(long M, int C) { return (long)sg_cdiv(M, bn_stats_rpb(M)) * 2 * C; }
 
 // sums (fp64, [2*C]) = per-channel sum and sum of squares over the M rows of x
 extern "C" int sg_bn_stats_sums(const float* x, long M, int C, float* workspace, double* sums, void* stream) {
   if (!x || !workspace || !sums || !chan_ok(C)) return SG_ERR_ARG;
-  const int rpb = 2048, nblk = sg_cdiv(M, rpb);
+  const int rpb = bn_stats_rpb(M), nblk = sg_cdiv(M, rpb);
   hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, workspace, M, C, rpb);
-  hipLaunchKernelGGL(k_bn_stats_combine, dim3(sg_cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, sums, nblk, C);
+  hipLaunchKernelGGL(k_bn_stats_combine, dim3(sg_cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, workspace, sums, nblk, C);
   return sg_launch_status();
 }
 
@@ -221,7 +237,8 @@ extern "C" int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x,
                                 const float* gamma, int gstride, float* dgamma, float* dbeta, double* chan, float* dgamma_c,
                                 float* dbeta_c, int B, int HW, int C, float eps, int relu, void* stream) {
   if (!dy || !x || !mean || !var || !gamma || !dgamma || !dbeta || !chan || !chan_ok(C) || (relu && !y)) return SG_ERR_ARG;
-  const int rpb = 512;
+  long r = ((long)HW * B + 511) / 512;                  // ~512 workgroups; <= HW / 16 float atomics per [b, c] address
+  const int rpb = (int)(r < 16 ? 16 : (r > 512 ? 512 : r));
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(sg_cdiv(HW, rpb), B), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, var, dgamma,
                      dbeta, HW, C, eps, relu, rpb);
   hipLaunchKernelGGL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan,

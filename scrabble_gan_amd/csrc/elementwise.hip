@@ -319,8 +319,10 @@ extern "C" int sg_gap_bwd(const float* dout, const float* x, float* dx, int B, i
 extern "C" int sg_bias_grad(const float* dy, float* db, long M, int N, void* stream) {
   if (!dy || !db || N < 1) return SG_ERR_ARG;
   if ((N & 3) == 0 && ((uintptr_t)dy & 15) == 0) {
-    int rpb = (int)(M / 1024);                    // ~1024 workgroups; 16..512 rows each
-    rpb = rpb < 16 ? 16 : (rpb > 512 ? 512 : rpb);
+    // <= 256 workgroups: every workgroup ends in one float atomic per column, and same-address atomics serialise
+    // (~90 ns each: 1024 adders per column cost more than the whole sweep)
+    long r = (M + 255) / 256;
+    const int rpb = (int)(r < 16 ? 16 : r);
     hipLaunchKernelGGL(k_bias_grad_v4, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
     return sg_launch_status();
   }

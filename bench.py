@@ -122,8 +122,11 @@ def main():
     fence()
     t0 = time.perf_counter()
     outs = []
+    host_enqueue = 0.0                                            # host time spent queuing the steps (no device waits in there)
     for i in range(args.steps):
+        t_q = time.perf_counter()
         outs.append(step(i))
+        host_enqueue += time.perf_counter() - t_q
         if i:
             tuple(outs[i - 1])                                    # read back step i-1 while step i runs
     fence()
@@ -157,6 +160,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1"
                                    % (B, L), "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
+            "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if L == 10 else None,      # reference-tape accounting
             "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if L == 10 else None,  # what the kernels actually run
         }

@@ -429,6 +429,8 @@ int sg_launch_igemm(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
     const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || ident);
     const bool narrow = tile_env == 64 || (tile_env == 0 && !can_split && t128 < 2048 && e64 > e128);
     if (narrow) return launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s);
+    static const int occ_env = getenv("SG_IGEMM_OCC") ? atoi(getenv("SG_IGEMM_OCC")) : 3;
+    if (occ_env == 4) return launch_cfg<128, 128, 2, 2, 16, 4>(a, b_nk, s);
     return launch_cfg<128, 128, 2, 2, 16, 3>(a, b_nk, s);
   }
   if (a.N > 32) {

@@ -15,7 +15,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // IDENT: both operands live on the base grid with unit sampling stride (every stride-1 Conv2D weight-grad): their
 // addresses are linear in the pixel index, so the k-loop needs one add per load; only the tap validity of P still
 // follows a (y, x) cursor.  The general form (strided sampling: transposed convolutions) keeps full cursors.
-template <int BC, int BN, int WM, int WN, int BK, int OCC, bool IDENT, bool QSCALE>
+// QSCALE: 0 = none; 1 = per-sample factor looked up per lane; 2 = the BK pixels of a k-tile always lie in ONE sample
+// (Hg*Wg % BK == 0: every layer of the fixed-shape step), so the factor is one wave-uniform load per k-tile
+template <int BC, int BN, int WM, int WN, int BK, int OCC, bool IDENT, int QSCALE>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgradArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
@@ -116,6 +118,10 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   };
   const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;     // one (tap, c-tile) column of workgroups sums dy
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QSCALE ? p.qscale : p.q), 0, QSCALE ? 4 * p.Bn : 0, 0x00020000);
+  unsigned vzero = 0;
+  asm volatile("" : "+v"(vzero));                                 // opaque per-lane zero: keeps the factor load on the vector path
+  int qs_b = m_begin / HW, qs_rem = m_begin - (m_begin / HW) * HW; // (QSCALE == 2) sample of the next k-tile
   auto load_q = [&]() {
 #pragma unroll
     for (int i = 0; i < Q_P; ++i) {
@@ -124,8 +130,14 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
       const unsigned off = IDENT ? q_lin[i] : 4u * (unsigned)(((qb[i] * p.Hq + qy[i] * p.q_sy) * p.Wq + qx[i] * p.q_sx) * p.Cq + qn);
       q_reg[i] = bload(rsrc_q, ok ? off : OOB);
       q_lin[i] += q_step;
-      if (QSCALE) q_sc[i] = p.qscale[ok ? qb[i] : 0];             // the per-sample factor is applied at the LDS store
-      if (!IDENT || QSCALE) advance(qb[i], qy[i], qx[i]);
+      if (QSCALE == 1) q_sc[i] = p.qscale[ok ? qb[i] : 0];        // the per-sample factor is applied at the LDS store
+      if (!IDENT || QSCALE == 1) advance(qb[i], qy[i], qx[i]);
+    }
+    if (QSCALE == 2) {
+      // a vector load (vmcnt, like the operands) of a uniform address: a scalar load would share the LDS wait counter
+      q_sc[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, (int)(vzero + 4u * (unsigned)qs_b), 0, 0));
+      qs_rem += BK;
+      if (qs_rem >= HW) { qs_rem -= HW; ++qs_b; }
     }
     m_next += BK;
   };
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
 #pragma unroll
     for (int i = 0; i < Q_P; ++i) {
       float4 v = q_reg[i];
-      if (QSCALE) { v.x *= q_sc[i]; v.y *= q_sc[i]; v.z *= q_sc[i]; v.w *= q_sc[i]; }
+      if (QSCALE) { const float sc = q_sc[QSCALE == 2 ? 0 : i]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
       bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;    // column sums of Q (used by the do_bias workgroups)
       *reinterpret_cast<float4*>(qs + (tid / (BN / 4) + i * Q_RPP) * BN + 4 * (tid % (BN / 4))) = v;
     }
@@ -282,10 +294,12 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   a.mchunk = (int)mchunk;
   const dim3 grid((unsigned)(combos * nchunks)), block(WM * WN * 64);
   const bool ident = wgrad_ident(a), qs = a.qscale != nullptr;
-  if (ident && qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, true>), grid, block, 0, s, a);
-  else if (ident) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, false>), grid, block, 0, s, a);
-  else if (qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, false>), grid, block, 0, s, a);
+  const bool qs_uniform = qs && ident && ((long)a.Hg * a.Wg) % BK == 0 && a.mchunk % BK == 0;
+  if (ident && qs_uniform) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 2>), grid, block, 0, s, a);
+  else if (ident && qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 1>), grid, block, 0, s, a);
+  else if (ident) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 0>), grid, block, 0, s, a);
+  else if (qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 0>), grid, block, 0, s, a);
   return sg_launch_status();
 }
 

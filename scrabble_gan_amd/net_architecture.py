@@ -208,13 +208,14 @@ class _DownTrunk:
 
 
 class DiscriminatorModel(_Model):
-    """make_discriminator / make_style_promoter body: trunk -> Dense(1, no bias)."""
+    """make_discriminator / make_style_promoter body: trunk -> Dense(1, no bias); make_style_extractor: Dense(128)."""
 
-    def __init__(self, name, input_dim, kernel_reg, blocks_with_attention):
+    def __init__(self, name, input_dim, kernel_reg, blocks_with_attention, units=1):
         h, w, c = input_dim
         self.trunk = _DownTrunk("B{}", blocks_with_attention, c, h, _DEFAULTS["nl_mode"])
         gen = _gen_for(name)
-        super().__init__(name, self.trunk.specs() + [("dense.w", (self.trunk.cout[-1], 1), nn.orthogonal, True)], gen)
+        super().__init__(name, self.trunk.specs() + [("dense.w", (self.trunk.cout[-1], units), nn.orthogonal, True)], gen)
+        self.units = units
         self.kernel_reg = kernel_reg
         self.nl_gen = torch.Generator().manual_seed(gen.initial_seed() + 7)
 
@@ -246,7 +247,7 @@ class DiscriminatorModel(_Model):
         """`wscale` [B]: the data-gradient chain runs with upstream `dlogits`, while sample b contributes to the weight
         gradients with `wscale[b] * dlogits[b]` -- one sweep serving two targets (backprop is linear per sample)."""
         tctx, h = ctx
-        dlogits = dlogits.reshape(-1, 1).contiguous()
+        dlogits = dlogits.reshape(-1, self.units).contiguous()
         if want_dw:
             dl_w = dlogits if wscale is None else ops.rowscale(dlogits, wscale)
             ops.dense_bwd_weight(h, dl_w, self.store.g["dense.w"])
@@ -553,6 +554,14 @@ def make_discriminator(input_dim, kernel_reg, blocks_with_attention, vis_model=T
 
 def make_style_promoter(input_dim, kernel_reg, blocks_with_attention, vis_model=True):
     m = DiscriminatorModel("style_promoter", input_dim, kernel_reg, blocks_with_attention)
+    if vis_model:
+        m.summary()
+    return m
+
+
+def make_style_extractor(input_dim, kernel_reg, blocks_with_attention, vis_model=True):
+    """The discriminator trunk with a 128-wide linear head (net_architecture.py:465-498); not used by main.py."""
+    m = DiscriminatorModel("style_extractor", input_dim, kernel_reg, blocks_with_attention, units=128)
     if vis_model:
         m.summary()
     return m

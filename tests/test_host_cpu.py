@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
         assert must in decls
     # pure host helpers may be called without a GPU
     assert lib.sg_spectral_norm_workspace_floats(9216, 1024) == 9216 + 1024 + 4
-    assert lib.sg_bn_stats_workspace_floats(4096, 64) == 2 * 2 * 64
+    assert lib.sg_bn_stats_workspace_floats(4096, 64) == 128 * 2 * 64          # 32 rows per workgroup: 128 partial blocks
+    assert lib.sg_bn_stats_workspace_floats(1 << 21, 64) == 1024 * 2 * 64      # capped at 2048 rows per workgroup
 
 
 def test_ops_fail_loudly_without_library(monkeypatch, tmp_path):
@@ -133,6 +134,7 @@ def test_reference_api_surface():
                                                                     "blocks_with_attention", "vocab_size", "vis_model"]
     assert list(inspect.signature(NA.make_discriminator).parameters) == ["input_dim", "kernel_reg", "blocks_with_attention", "vis_model"]
     assert list(inspect.signature(NA.make_style_promoter).parameters) == ["input_dim", "kernel_reg", "blocks_with_attention", "vis_model"]
+    assert list(inspect.signature(NA.make_style_extractor).parameters) == ["input_dim", "kernel_reg", "blocks_with_attention", "vis_model"]
     assert list(inspect.signature(NA.make_recognizer).parameters) == ["input_dim", "sequence_length", "output_classes", "vis_model"]
     assert list(inspect.signature(NA.make_my_recognizer).parameters) == ["input_dim", "sequence_length", "output_classes", "vis_model"]
     assert list(inspect.signature(NA.make_gan).parameters) == ["g_model", "d_model", "r_model", "w_model", "vis_model"]

@@ -94,6 +94,32 @@ def test_discriminator(setup, dev):
         close(D.store.g[k], v.grad, 1e-3, "grad " + k, at)
 
 
+def test_style_extractor(setup, dev):
+    """make_style_extractor (net_architecture.py:465-498) = the discriminator trunk with a 128-wide linear head."""
+    NA = setup
+    gen = torch.Generator().manual_seed(15)
+    E = NA.make_style_extractor((32, 160, 1), None, "B1", vis_model=False)
+    assert tuple(E.store.p["dense.w"].shape) == (1024, 128)
+    P = perturb(E, gen)
+    B, W = 2, 32
+    x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    nlo, nlg = nl_pair(64, gen, dev)
+    up = torch.randn(B, 128, generator=gen, dtype=torch.float64)
+    lv = leaves(P)
+    xr = x.clone().requires_grad_(True)
+    ref = O.discriminator(xr, P, nlo)
+    assert ref.shape == (B, 128)
+    (ref * up).sum().backward()
+    out, ctx = E.forward(x.float().to(dev), nlg)
+    close(out, ref, 1e-4, "style vector")
+    E.store.zero_grad()
+    dx = E.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+    close(dx, xr.grad, 1e-3, "dx")
+    at = net_atol([v.grad for v in lv.values()])
+    for k, v in lv.items():
+        close(E.store.g[k], v.grad, 1e-3, "grad " + k, at)
+
+
 def test_recognizer(setup, dev):
     NA = setup
     gen = torch.Generator().manual_seed(6)

@@ -45,6 +45,17 @@ int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float
 int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* ---- bf16 matrix-core variants (BASELINE config c3: bf16 MFMA convs, fp32 accumulation; activations, biases and
+ *      results stay fp32).  The filter is passed as a packed bf16 copy [tap][N][K] written by sg_pack_filter_bf16:
+ *        forward : pack(w, taps = kh*kw, K = Cin,  N = Cout, transpose = 1)
+ *        data-grad: pack(w, taps = kh*kw, K = Cout, N = Cin,  transpose = 0)
+ *      Restrictions: K % 8 == 0 and N > 32 (otherwise SG_ERR_UNSUPPORTED: use the fp32 entry point). ------------- */
+int sg_pack_filter_bf16(const float* w, void* out, int taps, int K, int N, int transpose, void* stream);
+int sg_conv2d_fwd_bf16(const float* x, const void* wp_fwd, const float* bias, const float* bias2, float* y,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, const float* mask, float* dx,
+                            int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+
 /* ---- layers.Conv2DTranspose(padding='same', strides=(sh,sw)) (resnet_ops.py:57,69) ------- */
 /* x [B,H,W,Cin] -> y [B,sh*H,sw*W,Cout]; k=3,s=2: y[2i+k] += x[i] w[k] cropped to 2n; bias everywhere */
 int sg_conv2d_transpose_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y,

@@ -109,6 +109,47 @@ def empty(*shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- convolutions
+# Matrix-core operand type of the 3x3 / 1x1 convolutions: "f32" (v_mfma_f32_32x32x2_f32, the parity mode) or "bf16"
+# (v_mfma_f32_32x32x16_bf16 with fp32 accumulation: BASELINE config c3).  Tensors in HBM are fp32 either way.
+CONV_DTYPE = "f32"
+_PACK_CACHE = {}
+
+
+def set_conv_dtype(dtype: str) -> None:
+    global CONV_DTYPE
+    if dtype not in ("f32", "bf16"):
+        raise ValueError("conv dtype must be 'f32' or 'bf16'")
+    CONV_DTYPE = dtype
+    _PACK_CACHE.clear()
+
+
+def weights_changed() -> None:
+    """Called by the optimizers (and anything else that rewrites parameters through raw pointers): the packed bf16
+    filter copies are stale."""
+    _PACK_CACHE.clear()
+
+
+def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
+    """bf16 copy [tap][N][K] of a Conv2D filter [kh,kw,Cin,Cout] for the forward ('fwd': K = Cin, N = Cout) or the
+    data-grad ('bwd': K = Cout, N = Cin) launch; made once per optimizer step."""
+    key = (w.data_ptr(), tuple(w.shape), kind, w._version)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    kh, kw, Cin, Cout = w.shape
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+    if kind == "fwd":
+        call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, Cin, Cout, 1, _stream())
+    else:
+        call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, Cout, Cin, 0, _stream())
+    _PACK_CACHE[key] = out
+    return out
+
+
+def _bf16_ok(K: int, N: int) -> bool:
+    return CONV_DTYPE == "bf16" and K % 8 == 0 and N > 32 and K > 1
+
+
 def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,
                out=None, accum=False):
     _chk(x, w, bias, bias2, out)
@@ -120,8 +161,12 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
         out = empty(B, Ho, Wo, Cout, like=x)
     with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
-        call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
-             _flags(relu_in, accum, relu_out, tanh_out), _stream())
+        if _bf16_ok(Cin, Cout) and not tanh_out:
+            call("sg_conv2d_fwd_bf16", _p(x), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout,
+                 kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
+        else:
+            call("sg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+                 _flags(relu_in, accum, relu_out, tanh_out), _stream())
     return out
 
 
@@ -135,8 +180,12 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
         out = empty(B, H, W, Cin, like=dy)
     with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
-        call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
-             _flags(accum=accum), _stream())
+        if _bf16_ok(Cout, Cin):
+            call("sg_conv2d_bwd_data_bf16", _p(dy), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out), B, H, W, Cin, Cout,
+                 kh, kw, int(same), _flags(accum=accum), _stream())
+        else:
+            call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),
+                 _flags(accum=accum), _stream())
     return out
 
 

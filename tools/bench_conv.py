@@ -40,8 +40,10 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--filter", default=None)
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS probe: same cycles, higher clock)")
+    ap.add_argument("--dtype", default="f32", help="f32 | bf16 (matrix-core operand type)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    ops.set_conv_dtype(args.dtype)
     B = args.batch
     print("%-12s %5s %5s %5s %5s | %9s %9s %9s   (TFLOP/s; ms)" % ("layer", "H", "W", "Cin", "Cout", "fwd", "dgrad", "wgrad"))
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}

@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-steps", type=int, default=2, help="N > 1 only: extra steps after the timed region for the per-kernel HIP-event timing")
+    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-core operand type of the convolutions: f32 = the headline config c2; bf16 = config c3 (run it with --batch 256)")
     ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
     ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
     args = ap.parse_args()
@@ -84,6 +86,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas
+    ops.set_conv_dtype(args.conv_dtype)
+    bf16 = args.conv_dtype == "bf16"
+    peak_tf = 2500.0 if bf16 else PEAK_FP32_MFMA_TF            # dense peaks of MI355X_MICROARCH.md's chip table
 
     in_dim = (32, 160, 1)
     G, D, R, S, gan = build_models(in_dim, 128, (32, 8192), None, "B3", "B1", 52, None)
@@ -157,8 +162,9 @@ def main():
         line = {
             "metric": metric, "value": value, "unit": "images/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1"
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": ("c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, fp32 tensors), hinge, disc_iters=1"
+                                    if bf16 else "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1")
                                    % (B, L), "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
             "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if L == 10 else None,      # reference-tape accounting
@@ -173,15 +179,18 @@ def main():
             # counters need their own rocprofv3 runs, so the figure is read back, not measured in this process)
             traffic, traffic_src = None, None
             try:
+                if bf16:
+                    raise FileNotFoundError
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_igemm_traffic_bs%d.json" % (B // world))))
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_igemm_traffic_bs%d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % (B // world)
             except Exception:  # noqa: BLE001
                 pass
-            line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s",
-                                "frac": ig["tflops"] / PEAK_FP32_MFMA_TF, "traffic": traffic, "traffic_source": traffic_src,
+            line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
+                                "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
                                 "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
                                 "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
-                                "kernel": "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)",
+                                "kernel": ("sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; transposed and <= 32-filter convs stay fp32)"
+                                           if bf16 else "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
                                 "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
                                 "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
             line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),

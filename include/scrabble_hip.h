@@ -30,6 +30,7 @@ extern "C" {
 #define SG_ACCUM 2     /* out += result                                                          */
 #define SG_RELU_OUT 4  /* max(.,0) applied to the result                                          */
 #define SG_TANH_OUT 8  /* tanh applied to the result (Cout == 1 path)                             */
+#define SG_MMA_BF16 256 /* sg_conv2d_bwd_weight: bf16 matrix-core operands, fp32 accumulation (config c3)  */
 
 /* ---- convolutions: layers.Conv2D stride 1 (bigacgan/resnet_ops.py:65,98,103,109;
  *      net_architecture.py:28-49,283; arch_ops.py:38-65 1x1) ------------------------------- */

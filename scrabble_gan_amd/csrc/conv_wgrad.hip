@@ -447,6 +447,11 @@ extern "C" int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
   for (int ky = 0; ky < kh; ++ky)
     for (int kx = 0; kx < kw; ++kx)
       a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  if (flags & SG_MMA_BF16) {            // bf16 matrix-core operands where the shape qualifies, fp32 otherwise
+    a.flags &= ~SG_MMA_BF16;
+    const int rc = sg_launch_wgrad_bf16(a, s);
+    if (rc != SG_ERR_UNSUPPORTED) return rc;
+  }
   return sg_launch_wgrad(a, s);
 }
 

@@ -15,6 +15,7 @@
 #define SG_ACCUM 2      // out += result instead of out = result
 #define SG_RELU_OUT 4   // apply max(.,0) to the result
 #define SG_TANH_OUT 8   // apply tanh to the result (thin Cout=1 path only)
+#define SG_MMA_BF16 256 // weight-grad: round the matrix-core operands to bf16 (fp32 accumulation); config c3
 
 static inline int sg_launch_status() {
   return hipGetLastError() == hipSuccess ? SG_OK : SG_ERR_LAUNCH;

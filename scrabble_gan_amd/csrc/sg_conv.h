@@ -61,3 +61,4 @@ struct SgThinArgs {
 
 int sg_launch_igemm(const SgIgemmArgs& a, bool b_nk, hipStream_t s);
 int sg_launch_wgrad(const SgWgradArgs& a, hipStream_t s);
+int sg_launch_wgrad_bf16(const SgWgradArgs& a, hipStream_t s);   // SG_ERR_UNSUPPORTED when the shape does not qualify

@@ -82,6 +82,7 @@ def main(argv=None):
     ap.add_argument("--gin", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
                                                   "scrabble_gan_mi355x.gin"))
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"], help="matrix-core operand type of the convolutions")
     ap.add_argument("--steps", type=int, default=None, help="cap batches per epoch")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
@@ -92,7 +93,7 @@ def main(argv=None):
     in_dim, buf_size, n_classes, seq_len, bucket_size, ckpt_path, gen_path, m_path, raw_dir, read_dir, char_vec = setup_io()
     epochs = args.epochs or epochs
     batch_size = args.batch_size or batch_size
-    configure()
+    configure(conv_dtype=args.conv_dtype)
 
     if args.synthetic:
         random_words = synthetic_random_words(bucket_size, 1000, n_classes)

@@ -50,8 +50,11 @@ def get_in_out_channels_disc(colors=1, resolution=32):
 _DEFAULTS = {"device": None, "seed": 0, "nl_mode": "reference", "reducer": LOCAL}
 
 
-def configure(device=None, seed=None, nl_mode=None, reducer=None):
-    """Process-wide construction defaults (device, init seed, NonLocalBlock mode, DP reducer)."""
+def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=None):
+    """Process-wide construction defaults (device, init seed, NonLocalBlock mode, DP reducer) and the matrix-core
+    operand type of the convolutions ('f32' = parity mode, 'bf16' = BASELINE config c3)."""
+    if conv_dtype is not None:
+        ops.set_conv_dtype(conv_dtype)
     if device is not None:
         _DEFAULTS["device"] = torch.device(device)
     if seed is not None:

@@ -12,6 +12,7 @@ import torch
 from ._lib import call, lib
 
 RELU_IN, ACCUM, RELU_OUT, TANH_OUT = 1, 2, 4, 8
+MMA_BF16 = 256
 BN_EPS = 1e-3
 
 
@@ -198,7 +199,8 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     assert wc == Cin and dy.shape[3] == Cout
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):
-        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in), _stream())
+        call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
+             _flags(relu_in) | (MMA_BF16 if CONV_DTYPE == "bf16" else 0), _stream())
 
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
@@ -509,11 +511,13 @@ def loss_grads(d_r, d_f, s_my, s_f, s_r, r_f, mode: int, balance: bool, alpha: f
 def adam_update(p, g, m, v, lr_t, beta_1, beta_2, eps=1e-7):
     _chk(p, g, m, v)
     call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
+    weights_changed()
 
 
 def rmsprop_update(p, g, ms, lr, rho=0.9, eps=1e-7):
     _chk(p, g, ms)
     call("sg_rmsprop_update", _p(p), _p(g), _p(ms), p.numel(), float(lr), float(rho), float(eps), _stream())
+    weights_changed()
 
 
 def spectral_norm(w, u, power_iteration=1):

@@ -82,3 +82,78 @@ def test_pack_filter_layouts(dev, gen, bf16_mode):
     assert ops.packed_filter(wg, "fwd") is ops.packed_filter(wg, "fwd")      # cached until the weights change
     ops.weights_changed()
     assert ops.packed_filter(wg, "fwd").data_ptr() != 0
+
+
+WGRAD_CASES = [
+    # B, H, W, Cin, Cout, k, scaled
+    (2, 8, 12, 64, 128, 3, False),
+    (3, 8, 16, 128, 256, 3, True),      # H*W = 128: one per-sample factor per 32-pixel k-tile (QSCALE 2)
+    (4, 4, 20, 256, 128, 3, True),      # H*W = 80: 32-pixel k-tiles straddle samples (QSCALE 1)
+    (2, 16, 80, 64, 512, 1, False),     # 1x1 shortcut
+    (5, 7, 5, 72, 96, 3, True),         # odd spatial dims, channel counts off the 128 tile
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,scaled", WGRAD_CASES)
+def test_conv2d_bf16_wgrad(dev, gen, bf16_mode, B, H, W, Cin, Cout, k, scaled):
+    ops = bf16_mode
+    x = rnd(gen, B, H, W, Cin)
+    dy = rnd(gen, B, H, W, Cout)
+    sc = torch.rand(B, generator=gen, dtype=torch.float64) * 2 - 0.5 if scaled else None
+    dys = dy if sc is None else dy * sc.view(B, 1, 1, 1)
+    base_w, base_b = rnd(gen, k, k, Cin, Cout), rnd(gen, Cout)
+
+    def oracle(xx, dd):
+        w = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        O.conv2d(xx, w, None).backward(dd)
+        return w.grad
+
+    dw, db = g32(base_w, dev), g32(base_b, dev)
+    ops.conv2d_bwd_weight(g32(x, dev), g32(dy, dev), dw, relu_in=True, db=db, sample_scale=None if sc is None else g32(sc, dev))
+    # the kernel rounds relu(x) and (factor * dy) to bf16; the bias gradient sums the fp32 values
+    dys32 = dy.float() if sc is None else dy.float() * sc.float().view(B, 1, 1, 1)      # the fp32 product the kernel rounds
+    ref_r = oracle(r16(torch.relu(x).float()), r16(dys32))
+    close(dw - g32(base_w, dev), ref_r, 1e-4, "dW vs bf16-rounded-operand oracle")
+    close(dw - g32(base_w, dev), oracle(torch.relu(x), dys), 1e-2, "dW vs exact oracle")
+    close(db - g32(base_b, dev), dys.sum(dim=(0, 1, 2)), 5e-5, "bias gradient (fp32 sums)")
+
+
+def test_train_step_bf16_tracks_fp32(dev, bf16_mode):
+    """One whole train_step with bf16 matrix-core convolutions against the same step in fp32 mode (same weights, inputs,
+    NonLocalBlock kernels): the 16 scalars agree to bf16 accuracy and every network's flat gradient points the same way."""
+    import numpy as np
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
+    ops = bf16_mode
+    NA.configure(device=dev, seed=3)
+    gen = torch.Generator().manual_seed(11)
+    B, L = 4, 2
+    images = (torch.rand(B, 32, 16 * L, 1, generator=gen) * 2 - 1).numpy()
+    style = (torch.rand(B, 32, 32, 1, generator=gen) * 2 - 1).numpy()
+    labels = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
+    fake = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
+    results = {}
+    for mode in ("f32", "bf16"):
+        ops.set_conv_dtype(mode)
+        NA._model_counter[0] = 0                       # identical initial weights in both runs
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+        gan = NA.make_gan(G, D, R, S, vis_model=False)
+        from scrabble_gan_amd import nn
+        g2 = torch.Generator().manual_seed(5)
+        nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
+              for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+        opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+        out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], style, B, 128,
+                            net_loss.hinge, 1, 0, None, 10, "", fake_labels=fake, nl=nl, verbose=False)
+        results[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))})
+    s32, g32_ = results["f32"]
+    s16, g16 = results["bf16"]
+    assert np.all(np.isfinite(s16))
+    assert np.all(np.abs(s16 - s32) <= 3e-2 * np.maximum(1.0, np.abs(s32))), (s16, s32)
+    for n in ("D", "R", "S", "G"):
+        a, b = g32_[n].double(), g16[n].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (a.norm() + 1e-30))
+        assert cos > (0.97 if n == "G" else 0.995), "%s: cosine %.5f, relative error %.3e" % (n, cos, rel)

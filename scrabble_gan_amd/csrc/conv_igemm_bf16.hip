@@ -158,12 +158,9 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_bf16_kernel(const S
     w_tap = 2 * p.taps[t].w_off;
   };
   if (p.ntaps > 0) set_tap();
-  const float relu_floor = relu_in ? 0.f : -__builtin_inff();
-  auto relu = [&](float v) {
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(relu_floor));
-    return r;
-  };
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const short rfloor = relu_in ? (short)0 : (short)0x8000;      // 0x8000 = most negative int16: ReLU off
+  const s16x4 rfloor4 = {rfloor, rfloor, rfloor, rfloor};
 
   auto load_tile = [&]() {        // fetch the k-tile at the cursor into registers, then advance the cursor
     const unsigned toff = (unsigned)(tap_off + 4 * lc0);
@@ -191,8 +188,10 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_bf16_kernel(const S
     for (int i = 0; i < A_P; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(&a_reg[i]);
       bf16x4 h;
-      h[0] = (__bf16)relu(v.x); h[1] = (__bf16)relu(v.y); h[2] = (__bf16)relu(v.z); h[3] = (__bf16)relu(v.w);
-      *reinterpret_cast<bf16x4*>(as + (arow0 + i * (NT / 8)) * LDK + 4 * kc) = h;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      // ReLU on the rounded operand: a bf16 is negative iff it is negative as an int16 -> packed 16-bit max
+      const s16x4 hr = __builtin_elementwise_max(__builtin_bit_cast(s16x4, h), rfloor4);
+      *reinterpret_cast<s16x4*>(as + (arow0 + i * (NT / 8)) * LDK + 4 * kc) = hr;
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i)

@@ -3,8 +3,8 @@
 //
 // The reduction index is the pixel m, which is the SLOW index of both NHWC operands, while the MFMA wants 8
 // consecutive reduction elements per lane.  So both operand tiles are transposed on their way into LDS: a thread
-// loads a 4-pixel x 4-channel block (four 16-byte rows), applies ReLU / the per-sample factor, rounds to bf16 and
-// writes four 8-byte column pieces Ps[c][m .. m+3] (row stride 40 elements: conflict-free 16-byte fragment reads).
+// loads an 8-pixel x 4-channel block (eight 16-byte rows), applies the per-sample factor, rounds to bf16, applies
+// ReLU and writes four 16-byte column pieces Xs[c][m .. m+7] (row stride 40 elements: conflict-free fragment reads).
 // Stride-1 convolutions only (both operands on the base grid: the IDENT form of sg_wgrad_kernel); the launcher
 // falls back to the fp32 kernel for everything else.  Pipeline as in sg_igemm_bf16_kernel: global loads one k-tile
 // (32 pixels) ahead in registers, LDS double buffer, fragment reads one k-step ahead.
@@ -16,7 +16,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// QSCALE: 0 = none, 1 = per-sample factor looked up per pixel row, 2 = one factor per k-tile (Hg*Wg % 32 == 0: the 32
+// QSCALE: 0 = none, 1 = per-sample factor looked up per 4-pixel group, 2 = one factor per k-tile (Hg*Wg % 32 == 0: the 32
 // pixels of a k-tile lie in one sample)
 template <int QSCALE>
 __global__ __launch_bounds__(256, 3) void sg_wgrad_bf16_kernel(const SgWgradArgs p) {
@@ -52,21 +52,28 @@ __global__ __launch_bounds__(256, 3) void sg_wgrad_bf16_kernel(const SgWgradArgs
     return *reinterpret_cast<const float4*>(&v);
   };
 
-  // thread -> 4x4 block: pixels 4*mq .. +3 of the k-tile, channels 4*cq .. +3 of the tile.  mq is the fast index, so
-  // the 8-byte LDS writes of a wave (8 mq x 8 cq) spread over all banks; a global load instruction touches
-  // 8 pixel rows x 128 contiguous bytes.
-  const int mq = tid & 7, cq = tid >> 3;          // 8 x 32
-  const int pc = c0 + 4 * cq, qn = n0 + 4 * cq;
-  const bool p_cok = pc < p.Cp, q_cok = qn < p.Cq;
-  // per-row pixel cursors of the 4 rows of this thread's block (tap validity of P follows (y, x))
-  int pb[4], py[4], px[4];
+  // Operand roles are split over the waves: waves 0-1 stage P, waves 2-3 stage Q (wave-uniform, so descriptors and
+  // constants are scalar selects).  A thread owns an 8-pixel x 4-channel block of its operand's k-tile: eight 16-byte
+  // row loads, then FOUR 16-byte LDS writes Xs[c][m .. m+7] (the LDS pipe, not the matrix cores or VALU, bounds this
+  // kernel: 8-byte column pieces cost twice the write slots).  The 8 pixels are two 4-pixel groups; Wg % 4 == 0
+  // (checked by the launcher) keeps each group inside one image row of one sample, so a group needs one (b, y, x) cursor.
+  const bool isP = __builtin_amdgcn_readfirstlane(tid) < 128;
+  const int u = tid & 127;
+  const int mq = u & 3, cq = u >> 2;                 // 4 pixel groups of 8 x 32 channel quads
+  const int oc = (isP ? c0 : n0) + 4 * cq;           // first channel of the block
+  const int oC = isP ? p.Cp : p.Cq;
+  const bool cok = oc < oC;
+  const int o_dy = isP ? dy : 0, o_dx = isP ? dx : 0;  // Q sits on the base grid: its validity test is always true
+  const auto rsrc_o = isP ? rsrc_p : rsrc_q;
+  unsigned short* const Xs = isP ? Ps : Qs;
+  int gb[2], gy[2], gx[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m_begin + 4 * mq + r;
-    pb[r] = m / HW;
-    const int rem = m - pb[r] * HW;
-    py[r] = rem / p.Wg;
-    px[r] = rem - py[r] * p.Wg;
+  for (int g = 0; g < 2; ++g) {
+    const int m = m_begin + 8 * mq + 4 * g;
+    gb[g] = m / HW;
+    const int rem = m - gb[g] * HW;
+    gy[g] = rem / p.Wg;
+    gx[g] = rem - gy[g] * p.Wg;
   }
   const int adv_b = BK / HW, adv_r = BK - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
   auto advance = [&](int& bb, int& yy, int& xx) {
@@ -78,70 +85,75 @@ __global__ __launch_bounds__(256, 3) void sg_wgrad_bf16_kernel(const SgWgradArgs
     yy -= cy * p.Hg;
     bb += adv_b + cy;
   };
-  unsigned p_lin = 4u * (unsigned)((m_begin + 4 * mq + dy * p.Wp + dx) * p.Cp + pc);
-  unsigned q_lin = 4u * (unsigned)((m_begin + 4 * mq) * p.Cq + qn);
-  const unsigned p_row = 4u * p.Cp, q_row = 4u * p.Cq;
-  const unsigned p_step = 4u * BK * p.Cp, q_step = 4u * BK * p.Cq;
+  unsigned o_lin = 4u * (unsigned)((m_begin + 8 * mq + o_dy * p.Wp + o_dx) * oC + oc);
+  const unsigned o_row = 4u * oC, o_step = 4u * BK * oC;
   int m_next = m_begin;
   unsigned vzero = 0;
   asm volatile("" : "+v"(vzero));
   int qs_b = m_begin / HW, qs_rem = m_begin - (m_begin / HW) * HW;
-  float q_sc = 1.f, q_sc4[4] = {1.f, 1.f, 1.f, 1.f};
+  float q_sc[2] = {1.f, 1.f};
 
-  float4 p_reg[4], q_reg[4];
-  const float relu_floor = relu_in ? 0.f : -__builtin_inff();
-  auto relu = [&](float v) {
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(relu_floor));
-    return r;
-  };
+  float4 o_reg[8];
   auto load_tile = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m_next + 4 * mq + r;
-      const int iy = py[r] + dy, ix = px[r] + dx;
-      const bool live = m < m_end;
-      const bool okp = live & p_cok & ((unsigned)iy < (unsigned)p.Hp) & ((unsigned)ix < (unsigned)p.Wp);
-      p_reg[r] = bload(rsrc_p, okp ? p_lin + r * p_row : OOB);
-      q_reg[r] = bload(rsrc_q, (live & q_cok) ? q_lin + r * q_row : OOB);
-      if (QSCALE == 1) q_sc4[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, live ? (int)(4u * (unsigned)pb[r]) : (int)OOB, 0, 0));
-      advance(pb[r], py[r], px[r]);
+    for (int g = 0; g < 2; ++g) {
+      const bool rowok = cok & ((unsigned)(gy[g] + o_dy) < (unsigned)p.Hp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool live = m_next + 8 * mq + 4 * g + r < m_end;
+        const bool ok = live & rowok & ((unsigned)(gx[g] + r + o_dx) < (unsigned)p.Wp);
+        o_reg[4 * g + r] = bload(rsrc_o, ok ? o_lin + (4 * g + r) * o_row : OOB);
+      }
+      if (QSCALE == 1)       // the group's sample
+        q_sc[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            rsrc_s, m_next + 8 * mq + 4 * g < m_end ? (int)(4u * (unsigned)gb[g]) : (int)OOB, 0, 0));
+      advance(gb[g], gy[g], gx[g]);
     }
-    p_lin += p_step;
-    q_lin += q_step;
+    o_lin += o_step;
     if (QSCALE == 2) {
-      q_sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, (int)(vzero + 4u * (unsigned)qs_b), 0, 0));
+      q_sc[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, (int)(vzero + 4u * (unsigned)qs_b), 0, 0));
+      q_sc[1] = q_sc[0];
       qs_rem += BK;
       if (qs_rem >= HW) { qs_rem -= HW; ++qs_b; }
     }
     m_next += BK;
   };
-  const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;
+  const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0 && !isP;     // the Q-staging waves of one (tap, c-tile) column sum dy
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ReLU on the ROUNDED operand, two elements per instruction: a bf16 is negative iff it is negative as an int16, so
+  // max(x, 0) is a packed signed 16-bit max (floor 0x8000 = most negative int16 switches it off; Q never takes it)
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const short rfloor = (relu_in && isP) ? (short)0 : (short)0x8000;
+  const s16x8 rfloor8 = {rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor};
   auto store_tile = [&](int buf) {
-    unsigned short* ps = Ps + buf * BC * LDK + (4 * cq) * LDK + 4 * mq;
-    unsigned short* qs = Qs + buf * BN * LDK + (4 * cq) * LDK + 4 * mq;
-    float4 pv[4], qv[4];
+    unsigned short* xs = Xs + buf * BC * LDK + (4 * cq) * LDK + 8 * mq;
+    float4 v[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pv[r] = make_float4(relu(p_reg[r].x), relu(p_reg[r].y), relu(p_reg[r].z), relu(p_reg[r].w));
-      qv[r] = q_reg[r];
-      if (QSCALE) { const float sc = QSCALE == 2 ? q_sc : q_sc4[r]; qv[r].x *= sc; qv[r].y *= sc; qv[r].z *= sc; qv[r].w *= sc; }
-      bsum.x += qv[r].x; bsum.y += qv[r].y; bsum.z += qv[r].z; bsum.w += qv[r].w;      // fp32 column sums of Q (bias gradient)
+    for (int r = 0; r < 8; ++r) {
+      v[r] = o_reg[r];
+      if (QSCALE) {                      // packed fp32 multiplies; the P waves multiply by 1
+        const float scr = isP ? 1.f : q_sc[r >> 2];
+        f32x2 lo = {v[r].x, v[r].y}, hi = {v[r].z, v[r].w};
+        const f32x2 sc = {scr, scr};
+        lo *= sc; hi *= sc;
+        v[r] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      }
     }
-    auto col = [](float a, float b, float c, float d) {
-      bf16x4 h;
-      h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
-      return h;
+    if (do_bias) {                       // wave-uniform: fp32 column sums of Q (bias gradient)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { bsum.x += v[r].x; bsum.y += v[r].y; bsum.z += v[r].z; bsum.w += v[r].w; }
+    }
+    auto col = [&](float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+      bf16x8 h;
+      h[0] = (__bf16)a0; h[1] = (__bf16)a1; h[2] = (__bf16)a2; h[3] = (__bf16)a3;
+      h[4] = (__bf16)a4; h[5] = (__bf16)a5; h[6] = (__bf16)a6; h[7] = (__bf16)a7;
+      return __builtin_elementwise_max(__builtin_bit_cast(s16x8, h), rfloor8);
     };
-    *reinterpret_cast<bf16x4*>(ps + 0 * LDK) = col(pv[0].x, pv[1].x, pv[2].x, pv[3].x);
-    *reinterpret_cast<bf16x4*>(ps + 1 * LDK) = col(pv[0].y, pv[1].y, pv[2].y, pv[3].y);
-    *reinterpret_cast<bf16x4*>(ps + 2 * LDK) = col(pv[0].z, pv[1].z, pv[2].z, pv[3].z);
-    *reinterpret_cast<bf16x4*>(ps + 3 * LDK) = col(pv[0].w, pv[1].w, pv[2].w, pv[3].w);
-    *reinterpret_cast<bf16x4*>(qs + 0 * LDK) = col(qv[0].x, qv[1].x, qv[2].x, qv[3].x);
-    *reinterpret_cast<bf16x4*>(qs + 1 * LDK) = col(qv[0].y, qv[1].y, qv[2].y, qv[3].y);
-    *reinterpret_cast<bf16x4*>(qs + 2 * LDK) = col(qv[0].z, qv[1].z, qv[2].z, qv[3].z);
-    *reinterpret_cast<bf16x4*>(qs + 3 * LDK) = col(qv[0].w, qv[1].w, qv[2].w, qv[3].w);
+    *reinterpret_cast<s16x8*>(xs + 0 * LDK) = col(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+    *reinterpret_cast<s16x8*>(xs + 1 * LDK) = col(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+    *reinterpret_cast<s16x8*>(xs + 2 * LDK) = col(v[0].z, v[1].z, v[2].z, v[3].z, v[4].z, v[5].z, v[6].z, v[7].z);
+    *reinterpret_cast<s16x8*>(xs + 3 * LDK) = col(v[0].w, v[1].w, v[2].w, v[3].w, v[4].w, v[5].w, v[6].w, v[7].w);
   };
 
   f32x16 acc[TM][TN];
@@ -201,19 +213,19 @@ __global__ __launch_bounds__(256, 3) void sg_wgrad_bf16_kernel(const SgWgradArgs
   if (kt + 1 < KT) { k_tile(kt & 1, std::true_type{}, std::false_type{}); ++kt; }
   if (kt < KT) k_tile(kt & 1, std::false_type{}, std::false_type{});
 
-  if (do_bias) {      // (block-uniform) reduce the per-thread column sums over the 8 pixel lanes, one atomic per column
+  if (p.dbias != nullptr && t == 0 && c0 == 0) {      // (block-uniform) reduce the Q waves' column sums over the 4 pixel lanes
     float4* red = reinterpret_cast<float4*>(smem);
     __syncthreads();
     red[tid] = bsum;
     __syncthreads();
-    if (mq == 0) {
+    if (!isP && mq == 0) {
       float4 s4 = red[tid];
-      for (int k = 1; k < 8; ++k) {
+      for (int k = 1; k < 4; ++k) {
         const float4 o = red[tid + k];
         s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
       }
-      if (qn < p.Cq) {
-        float* d = p.dbias + qn;
+      if (oc < p.Cq) {
+        float* d = p.dbias + oc;
         atomicAdd(d + 0, s4.x); atomicAdd(d + 1, s4.y); atomicAdd(d + 2, s4.z); atomicAdd(d + 3, s4.w);
       }
     }
@@ -239,7 +251,7 @@ int sg_launch_wgrad_bf16(const SgWgradArgs& a_in, hipStream_t s) {
   SgWgradArgs a = a_in;
   const bool ident = a.p_sy == 1 && a.p_sx == 1 && a.q_sy == 1 && a.q_sx == 1 && a.Hp == a.Hg && a.Wp == a.Wg && a.Hq == a.Hg && a.Wq == a.Wg;
   const long HW = (long)a.Hg * a.Wg;
-  if (!ident || a.Cp < 64 || a.Cq < 64 || (a.Cp & 3) || (a.Cq & 3) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS)
+  if (!ident || a.Cp < 64 || a.Cq < 64 || (a.Cp & 3) || (a.Cq & 3) || (a.Wg & 3) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS)
     return SG_ERR_UNSUPPORTED;
   const long M = (long)a.Bn * HW;
   const long p_elems = (long)a.Bn * a.Hp * a.Wp * a.Cp, q_elems = (long)a.Bn * a.Hq * a.Wq * a.Cq;

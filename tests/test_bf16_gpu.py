@@ -113,8 +113,11 @@ def test_conv2d_bf16_wgrad(dev, gen, bf16_mode, B, H, W, Cin, Cout, k, scaled):
     # the kernel rounds relu(x) and (factor * dy) to bf16; the bias gradient sums the fp32 values
     dys32 = dy.float() if sc is None else dy.float() * sc.float().view(B, 1, 1, 1)      # the fp32 product the kernel rounds
     ref_r = oracle(r16(torch.relu(x).float()), r16(dys32))
-    close(dw - g32(base_w, dev), ref_r, 1e-4, "dW vs bf16-rounded-operand oracle")
-    close(dw - g32(base_w, dev), oracle(torch.relu(x), dys), 1e-2, "dW vs exact oracle")
+    if W % 4:      # image rows that 4-pixel blocks would straddle: the launcher keeps the fp32 kernel (exact oracle, fp32 bar)
+        close(dw - g32(base_w, dev), oracle(torch.relu(x), dys), 1e-4, "dW (fp32 fallback) vs exact oracle")
+    else:
+        close(dw - g32(base_w, dev), ref_r, 1e-4, "dW vs bf16-rounded-operand oracle")
+        close(dw - g32(base_w, dev), oracle(torch.relu(x), dys), 1e-2, "dW vs exact oracle")
     close(db - g32(base_b, dev), dys.sum(dim=(0, 1, 2)), 5e-5, "bias gradient (fp32 sums)")
 
 

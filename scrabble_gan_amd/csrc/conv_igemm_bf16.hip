@@ -150,14 +150,21 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_bf16_kernel(const S
 
   using v4u = decltype(bload(rsrc_a, 0u));
   v4u a_reg[A_P], b_reg[B_P];
-  int lt = kt_begin / kchunks, lc0 = (kt_begin - (kt_begin / kchunks) * kchunks) * BK;
+  // channel-chunk-major reduction order, taps innermost, tap constants in an LDS table: see sg_igemm_kernel
+  __shared__ int tap_tab[2 * SG_MAX_TAPS];
+  if (tid < p.ntaps) {
+    tap_tab[2 * tid] = 4 * (p.taps[tid].dy * p.Wa + p.taps[tid].dx) * p.Ca;
+    tap_tab[2 * tid + 1] = 2 * p.taps[tid].w_off;
+  }
+  __syncthreads();
+  const int nt1 = p.ntaps > 0 ? p.ntaps : 1;
+  int lt = kt_begin % nt1, lc0 = (kt_begin / nt1) * BK;
   int tap_off = 0, w_tap = 0;
   auto set_tap = [&]() {
-    const int t = lt < p.ntaps ? lt : p.ntaps - 1;
-    tap_off = 4 * (p.taps[t].dy * p.Wa + p.taps[t].dx) * p.Ca;
-    w_tap = 2 * p.taps[t].w_off;
+    tap_off = tap_tab[2 * lt];
+    w_tap = tap_tab[2 * lt + 1];
   };
-  if (p.ntaps > 0) set_tap();
+  set_tap();
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   const short rfloor = relu_in ? (short)0 : (short)0x8000;      // 0x8000 = most negative int16: ReLU off
   const s16x4 rfloor4 = {rfloor, rfloor, rfloor, rfloor};
@@ -174,12 +181,11 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_bf16_kernel(const S
     const bool kok = lc0 + 8 * kc8 < p.Ca;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) b_reg[i] = bload(rsrc_w, (b_ok[i] && kok) ? b_off[i] + woff : OOB);
-    lc0 += BK;
-    if (lc0 >= p.Ca) {            // uniform
-      lc0 = 0;
-      ++lt;
-      set_tap();
-    }
+    ++lt;
+    const bool wrap = lt >= p.ntaps;
+    lt = wrap ? 0 : lt;
+    lc0 += wrap ? BK : 0;
+    set_tap();
   };
   auto store_tile = [&](int buf) {
     unsigned short* as = As + buf * BM * LDK;

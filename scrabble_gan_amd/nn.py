@@ -181,13 +181,24 @@ def nonlocal_weights_batch(requests, device) -> List[Dict[str, torch.Tensor]]:
     ONE asynchronous H2D copy, so the per-call re-draw of the reference (fact 3) costs no mid-step host sync.
     `requests` = [(C, generator), ...]."""
     host, shapes = [], []
-    for C, gen in requests:
-        for k, shp in (("theta", (1, 1, C, C // 8)), ("phi", (1, 1, C, C // 8)), ("g", (1, 1, C, C // 2)), ("o", (1, 1, C // 2, C))):
-            host.append(orthogonal(shp, gen).reshape(-1))
-            shapes.append((k, shp))
+    # The QRs are 64x8 .. 64x32: with a many-thread intra-op pool each costs ~1 ms of fork/join (6.6 ms per kernel set
+    # at 8 threads vs 0.3 ms at one), which would make the HOST the bottleneck of a small-batch step.
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for C, gen in requests:
+            for k, shp in (("theta", (1, 1, C, C // 8)), ("phi", (1, 1, C, C // 8)), ("g", (1, 1, C, C // 2)), ("o", (1, 1, C // 2, C))):
+                host.append(orthogonal(shp, gen).reshape(-1))
+                shapes.append((k, shp))
+    finally:
+        torch.set_num_threads(nthreads)
     flat = torch.cat(host)
     if device.type == "cuda":
-        flat = flat.pin_memory()
+        # staging buffer from torch's caching host allocator (reused across steps, guarded by its own events);
+        # Tensor.pin_memory() instead is a fresh hipHostMalloc per call: ~15 ms of host time per step
+        pinned = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
+        pinned.copy_(flat)
+        flat = pinned
     dev = flat.to(device, non_blocking=True)
     out, off, idx = [], 0, 0
     for _ in requests:

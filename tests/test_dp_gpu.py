@@ -106,3 +106,45 @@ def test_two_rank_step_equals_single_process(dev, balance, tmp_path):
         # fp32 summation order differs (per-rank partial sums, atomics): 1e-3 of the largest gradient
         assert err <= 1e-3 * scale, "%s gradients: max err %.3e vs scale %.3e" % (n, err, scale)
         assert werr <= 4.1e-4, n
+
+
+def _nccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from scrabble_gan_amd import ops
+        dev = torch.device("cuda:0")
+        # the collectives the data-parallel step issues, on the RCCL backend, interleaved with kernels of the C-ABI on
+        # torch's current stream: an fp32 flat gradient buffer (async), fp64 statistics (sync), then a consumer kernel
+        flat = torch.arange(1 << 20, device=dev, dtype=torch.float32) * 1e-3
+        ref = flat.clone()
+        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        stats = torch.full((12,), 3.5, device=dev, dtype=torch.float64)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        h.wait()
+        out = ops.add(flat, flat)
+        dist.barrier()
+        torch.cuda.synchronize()
+        ok = torch.equal(out, 2 * ref) and bool((stats == 3.5).all())
+        q.put(("ok" if ok else "FAIL", "values"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("FAIL", "%r\n%s" % (e, traceback.format_exc())))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_collectives():
+    """The 'nccl' (= RCCL) backend initialises on this box and runs the step's collective types (async fp32 flat
+    buffer, fp64 statistics, barrier) next to C-ABI kernels on torch's stream.  One rank only: RCCL needs one GPU per
+    rank, so the multi-rank semantics are covered by the gloo tests and the wire-up by this one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    status, msg = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", msg

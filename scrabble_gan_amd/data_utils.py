@@ -255,17 +255,27 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         dx = ops.add(dx_d, dx_s, out=dx_d)
         ctx_rf_ = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
         ops.add(dx, R.backward(ctx_rf_, gG_r, want_dx=True, want_dw=False), out=dx)
-        G.backward(ctx_g, dx)
+        # G's buffer is reduced in two slices: [zdense.w .. end] (filter bank, up blocks, head) as soon as it is final,
+        # under the style encoder's backward; [0 .. zdense.w) after it
+        g_tail = []
+        G.backward(ctx_g, dx, on_tail_ready=(lambda off: g_tail.append((off, red.all_reduce_sum_async(G.store.grad[off:]))))
+                   if red.world_size > 1 else None)
 
-    # ---- finish the gradient exchange, then the four updates ----
+    # ---- finish the gradient exchange and update: each network as soon as ITS exchange is done, so the updates of
+    #      D / R / S run under G's all-reduce ----
+    g_handles = []
     if g_step:
-        pending.append(red.all_reduce_sum_async(G.store.grad))
-    for h in pending:
+        if g_tail:
+            off, h_tail = g_tail[0]
+            g_handles = [red.all_reduce_sum_async(G.store.grad[:off]), h_tail]
+        else:
+            g_handles = [red.all_reduce_sum_async(G.store.grad)]
+    for h, opt, m in zip(pending, (discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer), (D, R, S)):
         red.wait(h)
-    discriminator_optimizer.apply_flat(D.store)
-    recognizer_optimizer.apply_flat(R.store)
-    stylepromoter_optimizer.apply_flat(S.store)
+        opt.apply_flat(m.store)
     if g_step:
+        for h in g_handles:
+            red.wait(h)
         generator_optimizer.apply_flat(G.store)
 
     if not sync:

@@ -342,7 +342,8 @@ class GeneratorModel(_Model):
         img = ops.conv2d_fwd(yb, p["final.w"], p["final.b"], tanh_out=True)        # :283-289
         return img, (tctx, h, z, y, up_ctx, bctx, yb, img)
 
-    def backward(self, ctx, dimg):
+    def backward(self, ctx, dimg, on_tail_ready=None):
+        """`on_tail_ready(offset)` (optional) is called once every gradient in `store.grad[offset:]` is final."""
         S, p, g = self.store, self.store.p, self.store.g
         tctx, h, z, y, up_ctx, bctx, yb, img = ctx
         d_pre = ops.tanh_bwd(img, dimg)
@@ -360,6 +361,10 @@ class GeneratorModel(_Model):
             d = nn.block_up_bwd(c, d, z, dz, i + 1, S, n, self.reducer)
         ops.filterbank_bwd(z, y, p["filter_bank"], d, g["filter_bank"], dz)
         ops.dense_bwd_weight(h, dz, g["zdense.w"])
+        if on_tail_ready is not None:
+            # every gradient from zdense.w to the end of the flat buffer (filter bank, up blocks, final BN / conv) is
+            # complete: data parallelism starts reducing that slice while the style encoder's backward still runs
+            on_tail_ready(S._off["zdense.w"])
         dh = ops.dense_bwd_input(dz, p["zdense.w"])
         self.trunk.bwd(tctx, dh, S, want_dx=False, want_dw=True)
 

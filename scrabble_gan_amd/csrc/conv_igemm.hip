@@ -28,6 +28,7 @@ __device__ __forceinline__ int sg_xcd_remap(int orig, int nwg) {
 }
 
 #define SG_IDENT_OUT 32   // internal flag: output pixel == base-grid pixel (idx = m*N + n, no div/mod)
+#define SG_PREZEROED 64   // internal flag: the caller zeroed the whole output: partial tiles may be added without a memset
 
 template <int BM, int BN, int WM, int WN, bool B_NK, int BK, int OCC>
 __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgemmArgs p) {
@@ -358,7 +359,7 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   const int KT_all = a.ntaps * sg_cdiv(a.Ca, BK);
   // partial sums need a linear epilogue and an output that is zero (or holds the accumulate operand) beforehand;
   // strided output placement (transposed convolution classes) is only split when it accumulates
-  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG_IDENT_OUT));
+  const bool can_split = !(a.flags & SG_RELU_OUT) && (a.flags & (SG_ACCUM | SG_IDENT_OUT | SG_PREZEROED));
   // Balance model: workgroups are handed to the 256 CUs round-robin and share a CU's matrix pipes, so a launch of T
   // equal tiles takes ceil(T / 256) tile-times.  The tiles beyond the last multiple of 256 (all of them when T < 256)
   // are cut `sp` ways along the reduction, sp chosen to minimise ceil(tail * sp / 256) / sp, with a small charge per
@@ -397,7 +398,7 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
       }
     }
   }
-  if (nsplit > 1 && !(a.flags & SG_ACCUM)) {         // zero the rows the partial tiles add into (IDENT_OUT: one contiguous range)
+  if (nsplit > 1 && !(a.flags & (SG_ACCUM | SG_PREZEROED))) {   // zero the rows the partial tiles add into (IDENT_OUT: one contiguous range)
     const size_t row0 = (size_t)(full / n_tiles) * BM;
     if (hipMemsetAsync(a.out + row0 * a.N, 0, sizeof(float) * ((size_t)M - row0) * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
   }
@@ -434,7 +435,7 @@ int sg_launch_igemm(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
     const double e128 = (double)t128 / (((t128 + 255) / 256) * 256.0);
     const double e64 = 0.93 * (double)t64 / (((t64 + 255) / 256) * 256.0);
     const bool ident = a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg;
-    const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || ident);
+    const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & (SG_ACCUM | SG_PREZEROED)) || ident);
     const bool narrow = tile_env == 64 || (tile_env == 0 && !can_split && t128 < 2048 && e64 > e128);
     if (narrow) return launch_cfg<128, 64, 2, 2, 16, 4>(a, b_nk, s);
     static const int occ_env = getenv("SG_IGEMM_OCC") ? atoi(getenv("SG_IGEMM_OCC")) : 3;
@@ -669,6 +670,13 @@ extern "C" int sg_conv2d_transpose_fwd(const float* x, const float* w, const flo
                                        void* stream) {
   if (!x || !w || !y || kh * kw > SG_MAX_TAPS || sh < 1 || sw < 1) return SG_ERR_ARG;
   const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  // Small per-GPU batches leave each parity-class launch with a few dozen tiles.  The classes write disjoint pixels of
+  // y, so y is zeroed ONCE here and every class may then cut its tiles along the reduction (atomic partial tiles).
+  const long M1 = (long)B * H * W;
+  if (!(flags & SG_ACCUM) && sh * sw > 1 && sg_cdiv(M1, 128) * sg_cdiv(Cout, 128) < 256) {
+    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)M1 * sh * sw * Cout, (hipStream_t)stream) != hipSuccess) return SG_ERR_LAUNCH;
+    flags |= SG_PREZEROED;
+  }
   for (int py = 0; py < sh; ++py)
     for (int px = 0; px < sw; ++px) {
       SgIgemmArgs a{};

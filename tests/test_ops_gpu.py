@@ -132,6 +132,8 @@ CONVT_CASES = [
     (2, 4, 8, 64, 32, 1, (2, 2)),
     (2, 4, 8, 64, 32, 1, (2, 1)),
     (1, 8, 20, 256, 128, 3, (2, 2)),
+    (4, 4, 40, 512, 256, 3, (2, 2)),    # the 8-way-shard shape of G.B1: few tiles per parity class -> pre-zeroed output, split reduction
+    (4, 8, 80, 256, 128, 3, (2, 1)),
 ]
 
 

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--timing-steps", type=int, default=2, help="N > 1 only: extra steps after the timed region for the per-kernel HIP-event timing")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
                     help="matrix-core operand type of the convolutions: f32 = the headline config c2; bf16 = config c3 (run it with --batch 256)")
+    ap.add_argument("--bucketed", action="store_true",
+                    help="config c4: one (L_r, L_f) pair per step drawn U{4..23}^2 from a stream shared by all ranks (bucket_size 23)")
     ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
     ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
     args = ap.parse_args()
@@ -96,7 +98,7 @@ def main():
 
     B, L = args.batch, args.L
     images, labels, my_imgs = DU.synthetic_batch(B, L, in_dim, 52, seed=0)
-    words = DU.synthetic_random_words(10, 1000, 52, seed=0)
+    words = DU.synthetic_random_words(max(10, L), 1000, 52, seed=0)
     random.seed(0)
     fake = np.array([random.choice(words[L - 1]) for _ in range(B)], np.int32)      # random_bucket_idx forced to L-1
     # inputs resident in HBM before the timed region; every rank holds the global batch and takes its slice
@@ -105,9 +107,25 @@ def main():
 
     # sync="lazy": the 16 scalars of a step come back by an asynchronous copy and are read after the next step has
     # been queued (as scrabble_gan_amd.data_utils.train does); every step's values are read and checked below.
+    pools = None
+    if args.bucketed:          # variable-width words: inputs of every bucket resident in HBM, the per-step pair from a shared stream
+        words23 = DU.synthetic_random_words(23, 1000, 52, seed=0)
+        pools = {}
+        for Lb in range(4, 24):
+            im, lb, _ = DU.synthetic_batch(B, Lb, in_dim, 52, seed=Lb)
+            fk = np.array([random.choice(words23[Lb - 1]) for _ in range(B)], np.int32)
+            pools[Lb] = (torch.from_numpy(im).to(dev), torch.from_numpy(lb).to(dev), torch.from_numpy(fk).to(dev))
+        pair_rng = np.random.default_rng(7)
+        pairs = [tuple(int(v) for v in pair_rng.integers(4, 24, 2)) for _ in range(args.warmup + args.steps + args.timing_steps)]
+
     def step(i):
+        if pools is not None:
+            L_r, L_f = pairs[i % len(pairs)]
+            return DU.train_step(0, i, args.steps, pools[L_r][0], pools[L_r][1], D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d,
+                                 B, 128, net_loss.hinge, 1, 0, words, 23, "", fake_labels=pools[L_f][2], verbose=False,
+                                 sync=True if args.sync_every_step else "lazy")
         return DU.train_step(0, i, args.steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
-                             net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake_d, verbose=False,
+                             net_loss.hinge, 1, 0, words, max(10, L), "", fake_labels=fake_d, verbose=False,
                              sync=True if args.sync_every_step else "lazy")
 
     def fence():
@@ -117,7 +135,7 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        step(i - args.warmup)            # negative indices: the warm-up draws its own pairs in --bucketed mode
     # Kernel timing (HIP events around every MFMA conv launch, on the launch stream) runs inside the timed region at
     # N = 1.  At N > 1 the per-GPU batch is small enough for the event records to cost a few percent, so there the
     # timed region runs bare and the roofline figures come from --timing-steps extra steps right after it.
@@ -165,10 +183,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": ("c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, fp32 tensors), hinge, disc_iters=1"
                                     if bf16 else "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1")
-                                   % (B, L), "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
+                                   % (B, L) if not args.bucketed else
+                                   "c4: synthetic random_words 32x(16 L), (L_r, L_f) ~ U{4..23}^2 per step, global bs %d, %s MFMA convs" % (B, args.conv_dtype),
+                                   "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
-            "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if L == 10 else None,      # reference-tape accounting
-            "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if L == 10 else None,  # what the kernels actually run
+            "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if (L == 10 and not args.bucketed) else None,      # reference-tape accounting
+            "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if (L == 10 and not args.bucketed) else None,  # what the kernels actually run
         }
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True

@@ -160,3 +160,34 @@ def test_train_step_bf16_tracks_fp32(dev, bf16_mode):
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         rel = float((a - b).norm() / (a.norm() + 1e-30))
         assert cos > (0.97 if n == "G" else 0.995), "%s: cosine %.5f, relative error %.3e" % (n, cos, rel)
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,k", [(16, 80, 512, 512, 3), (8, 40, 1024, 1024, 3), (4, 20, 1024, 1024, 3), (16, 80, 64, 512, 3),
+                                           (8, 40, 512, 1024, 1)])
+def test_bf16_kernels_full_size_on_bf16_representable_inputs(dev, bf16_mode, H, W, Cin, Cout, k):
+    """BASELINE sizes (bs 128).  With operands that ARE bf16 values the rounding inside the bf16 kernels is the identity,
+    so forward / data-grad / weight-grad must (1) agree with the fp32 kernels up to fp32 summation order and (2) satisfy
+    the adjoint identity <conv(x,w),dy> == <x,dgrad> == <w,wgrad> -- size-independent checks of the bf16 path."""
+    from tests.test_fullsize_gpu import dot, rel
+    ops = bf16_mode
+    B = 128
+    g = torch.Generator(device=dev).manual_seed(H * W + Cin + 1)
+    q = lambda t: t.to(torch.bfloat16).float()
+    x = q(torch.randn(B, H, W, Cin, device=dev, generator=g))
+    w = q(torch.randn(k, k, Cin, Cout, device=dev, generator=g) / (k * Cin ** 0.5))
+    dy = q(torch.randn(B, H, W, Cout, device=dev, generator=g))
+    res = {}
+    for mode in ("bf16", "f32"):
+        ops.set_conv_dtype(mode)
+        y = ops.conv2d_fwd(x, w)
+        dx = ops.conv2d_bwd_data(dy, w, (H, W))
+        dw = torch.zeros_like(w)
+        ops.conv2d_bwd_weight(x, dy, dw)
+        res[mode] = (y, dx, dw)
+    ops.set_conv_dtype("bf16")
+    for name, a, b in zip(("y", "dx", "dw"), res["bf16"], res["f32"]):
+        err = (a - b).abs().max().item()
+        assert err <= 2e-4 * b.abs().max().item(), "%s: bf16 kernel vs fp32 kernel %.3e (scale %.3e)" % (name, err, b.abs().max().item())
+    y, dx, dw = res["bf16"]
+    a, b, c = dot(y, dy), dot(x, dx), dot(w, dw)
+    assert rel(a, b) < 2e-3 and rel(a, c) < 2e-3, (a, b, c)

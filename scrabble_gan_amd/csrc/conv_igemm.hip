@@ -343,6 +343,14 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_igemm_kernel(const SgIgem
   }
 }
 
+__global__ __launch_bounds__(256) void k_relu_inplace(float* x, long n4) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<float4*>(x)[e];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    reinterpret_cast<float4*>(x)[e] = v;
+  }
+}
+
 static int g_split_override = -1;   // tuning/debug: -1 = heuristic, 1 = never split, n > 1 = force n splits
 extern "C" void sg_debug_set_splitk(int n) { g_split_override = n; }
 
@@ -359,6 +367,14 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   const int KT_all = a.ntaps * sg_cdiv(a.Ca, BK);
   // partial sums need a linear epilogue and an output that is zero (or holds the accumulate operand) beforehand;
   // strided output placement (transposed convolution classes) is only split when it accumulates
+  // A fused output ReLU is not linear in the partial sums.  Where the grid cannot fill the chip (recognizer convs at
+  // small per-GPU batches: a few dozen tiles) the launch is split anyway and the ReLU runs as a separate in-place
+  // sweep over the (small) result afterwards.
+  bool relu_after = false;
+  if ((a.flags & SG_RELU_OUT) && (a.flags & SG_IDENT_OUT) && !(a.flags & SG_ACCUM) && !(a.N & 3) && tiles < 2 * 256 && KT_all >= 32 && split_env != 1) {
+    a.flags &= ~SG_RELU_OUT;
+    relu_after = true;
+  }
   const bool can_split = !(a.flags & SG_RELU_OUT) && (a.flags & (SG_ACCUM | SG_IDENT_OUT | SG_PREZEROED));
   // Balance model: workgroups are handed to the 256 CUs round-robin and share a CU's matrix pipes, so a launch of T
   // equal tiles takes ceil(T / 256) tile-times.  The tiles beyond the last multiple of 256 (all of them when T < 256)
@@ -410,6 +426,10 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
     hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   else
     hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
+  if (relu_after) {
+    const long n4 = M * a.N / 4;         // N % 4 == 0 on this path ([K,N] filters) or the tensor is padded to float4 by NHWC C % 4
+    hipLaunchKernelGGL(k_relu_inplace, dim3(sg_grid_for(n4, 256)), dim3(256), 0, s, a.out, n4);
+  }
   return sg_launch_status();
 }
 

@@ -156,19 +156,20 @@ def main():
     tuple(outs[-1])
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
+    if world > 1:                      # the measurement proper is complete here: MAX over ranks first, extras afterwards
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    assert all(np.isfinite(float(v)) for o in outs for v in o), outs
     timed_steps = args.steps
     if timer is not None and not timing_in_region:
         ops.PROFILER = timer
         extra = [step(args.steps + i) for i in range(args.timing_steps)]
         fence()
         ops.PROFILER = None
-        outs.extend(extra)
         timed_steps = args.timing_steps
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
-    assert all(np.isfinite(float(v)) for o in outs for v in o), outs
+        for o in extra:
+            tuple(o)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -193,28 +194,31 @@ def main():
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True
         if timer is not None:
-            ks = timer.summary()
-            ig = ks.get("igemm", {"tflops": 0.0, "launches": 0, "ms": 0.0})
-            # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
-            # counters need their own rocprofv3 runs, so the figure is read back, not measured in this process)
-            traffic, traffic_src = None, None
             try:
-                if bf16:
-                    raise FileNotFoundError
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_igemm_traffic_bs%d.json" % (B // world))))
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_igemm_traffic_bs%d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % (B // world)
-            except Exception:  # noqa: BLE001
-                pass
-            line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
-                                "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
-                                "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
-                                "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
-                                "kernel": ("sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; transposed and <= 32-filter convs stay fp32)"
-                                           if bf16 else "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
-                                "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
-                                "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
-            line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
-                                   "launches_per_step": v["launches"] / timed_steps} for k, v in ks.items()}
+                ks = timer.summary()
+                ig = ks.get("igemm", {"tflops": 0.0, "launches": 0, "ms": 0.0})
+                # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
+                # counters need their own rocprofv3 runs, so the figure is read back, not measured in this process)
+                traffic, traffic_src = None, None
+                try:
+                    if bf16:
+                        raise FileNotFoundError
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_igemm_traffic_bs%d.json" % (B // world))))
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_igemm_traffic_bs%d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % (B // world)
+                except Exception:  # noqa: BLE001
+                    pass
+                line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
+                                    "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
+                                    "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
+                                    "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
+                                    "kernel": ("sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; transposed and <= 32-filter convs stay fp32)"
+                                               if bf16 else "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
+                                    "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
+                                    "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
+                line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
+                                       "launches_per_step": v["launches"] / timed_steps} for k, v in ks.items()}
+            except Exception as e:  # noqa: BLE001  (the headline numbers above must still be printed)
+                line["roofline_error"] = repr(e)
         if timer is not None and args.shape_table:
             with open(args.shape_table, "w") as f:
                 f.write("# per-shape MFMA conv launches inside train_step, per-GPU batch %d, %d steps (HIP events on the launch stream)\n" % (B // world, timed_steps))
@@ -222,7 +226,10 @@ def main():
                 for fam, tag, n, ms_, tf in timer.by_shape():
                     f.write("%-7s %-12s %5d %4d %4d %5d %5d %2d | %4d %9.3f %8.1f\n" % ((fam,) + tuple(tag) + (n // timed_steps, ms_ / timed_steps, tf)))
         if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -202,6 +202,167 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small-batch variants (per-GPU batches of the 8-way data-parallel shard): 64 queries per workgroup, and the FOUR
+// waves of the workgroup split the KEYS of those queries (wave w takes key tiles w, w+4, ...), each with a private
+// LDS tile; the partial softmax states are merged through LDS at the end.  4x the parallelism of one wave per 64
+// queries, a quarter of the serial key loop.
+// ------------------------------------------------------------------------------------------
+#define AT_KS 64    // keys per wave-private LDS tile
+
+__global__ __launch_bounds__(256) void k_attn_fwd_ks(const float* theta, const float* phi, const float* g, float* out, float* lse,
+                                                     int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) float sm[4 * AT_KS * (AT_DK + AT_DV)];      // 40 KB: 4 x (K tile + V tile)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ks = sm + wave * AT_KS * (AT_DK + AT_DV);
+  float* vs = ks + AT_KS * AT_DK;
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 64 + lane;
+  const bool live = qi < Nq;
+  float q[AT_DK];
+#pragma unroll
+  for (int d = 0; d < AT_DK; ++d) q[d] = live ? theta[((size_t)b * Nq + qi) * AT_DK + d] : 0.f;
+  float m = -INFINITY, l = 0.f, acc[AT_DV];
+#pragma unroll
+  for (int c = 0; c < AT_DV; ++c) acc[c] = 0.f;
+
+  for (int k0 = wave * AT_KS; k0 < Nk; k0 += 4 * AT_KS) {        // wave-uniform trip count; no workgroup barrier inside
+    const int kn = min(AT_KS, Nk - k0);
+    for (int e = lane; e < AT_KS * AT_DK / 4; e += 64)
+      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
+          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lane; e < AT_KS * AT_DV / 4; e += 64)
+      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
+          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    for (int j0 = 0; j0 < kn; j0 += 8) {
+      float s[8];
+      float mx = m;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float4 ka = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2];
+        const float4 kb = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2 + 1];
+        float t = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
+        if (j0 + jj >= kn) t = -INFINITY;
+        s[jj] = t;
+        mx = fmaxf(mx, t);
+      }
+      const float sc = expf(m - mx);
+      l *= sc;
+#pragma unroll
+      for (int c = 0; c < AT_DV; ++c) acc[c] *= sc;
+      m = mx;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float p = expf(s[jj] - m);
+        l += p;
+        const float4* vp = reinterpret_cast<const float4*>(vs + (j0 + jj) * AT_DV);
+#pragma unroll
+        for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
+          const float4 v = vp[c4];
+          acc[4 * c4 + 0] += p * v.x; acc[4 * c4 + 1] += p * v.y; acc[4 * c4 + 2] += p * v.z; acc[4 * c4 + 3] += p * v.w;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // merge the four partial states of each query: sm is re-used as part[w][34][64]
+  __syncthreads();
+  float* part = sm + wave * (AT_DV + 2) * 64;
+  part[0 * 64 + lane] = m;
+  part[1 * 64 + lane] = l;
+#pragma unroll
+  for (int c = 0; c < AT_DV; ++c) part[(2 + c) * 64 + lane] = acc[c];
+  __syncthreads();
+  if (wave == 0 && live) {
+    float ms = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ms = fmaxf(ms, sm[w * (AT_DV + 2) * 64 + lane]);
+    float lt = 0.f, o[AT_DV];
+#pragma unroll
+    for (int c = 0; c < AT_DV; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* pw = sm + w * (AT_DV + 2) * 64;
+      const float f = expf(pw[lane] - ms);          // exp(-inf) = 0 for a wave that saw no key
+      lt += pw[64 + lane] * f;
+#pragma unroll
+      for (int c = 0; c < AT_DV; ++c) o[c] += pw[(2 + c) * 64 + lane] * f;
+    }
+    const float inv = 1.f / lt;
+    float4* op = reinterpret_cast<float4*>(out + ((size_t)b * Nq + qi) * AT_DV);
+#pragma unroll
+    for (int c4 = 0; c4 < AT_DV / 4; ++c4)
+      op[c4] = make_float4(o[4 * c4] * inv, o[4 * c4 + 1] * inv, o[4 * c4 + 2] * inv, o[4 * c4 + 3] * inv);
+    lse[(size_t)b * Nq + qi] = ms + logf(lt);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_ks(const float* theta, const float* phi, const float* g, const float* out,
+                                                        const float* lse, const float* dout, float* dtheta, float* delta, int Nq, int Nk) {
+  __shared__ __attribute__((aligned(16))) float sm[4 * AT_KS * (AT_DK + AT_DV)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ks = sm + wave * AT_KS * (AT_DK + AT_DV);
+  float* vs = ks + AT_KS * AT_DK;
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 64 + lane;
+  const bool live = qi < Nq;
+  const size_t row = (size_t)b * Nq + (live ? qi : 0);
+  float q[AT_DK], dq[AT_DK], dO[AT_DV];
+#pragma unroll
+  for (int d = 0; d < AT_DK; ++d) { q[d] = live ? theta[row * AT_DK + d] : 0.f; dq[d] = 0.f; }
+  float dl = 0.f;
+#pragma unroll
+  for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
+    const float4 a = reinterpret_cast<const float4*>(dout + row * AT_DV)[c4];
+    const float4 o = reinterpret_cast<const float4*>(out + row * AT_DV)[c4];
+    dO[4 * c4] = a.x; dO[4 * c4 + 1] = a.y; dO[4 * c4 + 2] = a.z; dO[4 * c4 + 3] = a.w;
+    dl += a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
+  }
+  const float ls = lse[row];
+  for (int k0 = wave * AT_KS; k0 < Nk; k0 += 4 * AT_KS) {
+    const int kn = min(AT_KS, Nk - k0);
+    for (int e = lane; e < AT_KS * AT_DK / 4; e += 64)
+      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
+          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lane; e < AT_KS * AT_DV / 4; e += 64)
+      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
+          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < kn; ++j) {
+      const float4 ka = reinterpret_cast<const float4*>(ks)[j * 2], kb = reinterpret_cast<const float4*>(ks)[j * 2 + 1];
+      const float s = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
+      const float p = expf(s - ls);
+      float dp = 0.f;
+      const float4* vp = reinterpret_cast<const float4*>(vs + j * AT_DV);
+#pragma unroll
+      for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
+        const float4 v = vp[c4];
+        dp += dO[4 * c4] * v.x + dO[4 * c4 + 1] * v.y + dO[4 * c4 + 2] * v.z + dO[4 * c4 + 3] * v.w;
+      }
+      const float ds = p * (dp - dl);
+      dq[0] += ds * ka.x; dq[1] += ds * ka.y; dq[2] += ds * ka.z; dq[3] += ds * ka.w;
+      dq[4] += ds * kb.x; dq[5] += ds * kb.y; dq[6] += ds * kb.z; dq[7] += ds * kb.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();                       // partial dq of the four key slices: plain sum (lse is already final)
+  float* part = sm + wave * AT_DK * 64;
+#pragma unroll
+  for (int d = 0; d < AT_DK; ++d) part[d * 64 + lane] = dq[d];
+  __syncthreads();
+  if (wave == 0 && live) {
+    float r[AT_DK];
+#pragma unroll
+    for (int d = 0; d < AT_DK; ++d)
+      r[d] = sm[d * 64 + lane] + sm[(AT_DK + d) * 64 + lane] + sm[(2 * AT_DK + d) * 64 + lane] + sm[(3 * AT_DK + d) * 64 + lane];
+    float4* dp4 = reinterpret_cast<float4*>(dtheta + row * AT_DK);
+    dp4[0] = make_float4(r[0], r[1], r[2], r[3]);
+    dp4[1] = make_float4(r[4], r[5], r[6], r[7]);
+    delta[row] = dl;
+  }
+}
+
 // one lane per row; 64-lane workgroups when 256-lane ones would leave most of the 256 CUs idle
 static inline int at_threads(int rows, int B) { return (long)sg_cdiv(rows, 256) * B >= 1024 ? 256 : 64; }
 
@@ -210,7 +371,10 @@ extern "C" int sg_attention_fwd(const float* theta, const float* phi, const floa
                                 int Nk, int dk, int dv, void* stream) {
   if (!theta || !phi || !g || !out || !lse || dk != AT_DK || dv != AT_DV || Nk < 1) return SG_ERR_ARG;
   const int tq = at_threads(Nq, B);
-  hipLaunchKernelGGL(k_attn_fwd, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
+  if (tq == 64)      // small batch: 64 queries per workgroup, keys split over its four waves
+    hipLaunchKernelGGL(k_attn_fwd_ks, dim3(sg_cdiv(Nq, 64), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
+  else
+    hipLaunchKernelGGL(k_attn_fwd, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
   return sg_launch_status();
 }
 
@@ -221,8 +385,12 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   if (!theta || !phi || !g || !out || !lse || !dout || !dtheta || !dphi || !dg || !delta || dk != AT_DK || dv != AT_DV || Nk < 1)
     return SG_ERR_ARG;
   const int tq = at_threads(Nq, B), tk = at_threads(Nk, B);
-  hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
-                     dtheta, delta, Nq, Nk);
+  if (tq == 64)
+    hipLaunchKernelGGL(k_attn_bwd_dq_ks, dim3(sg_cdiv(Nq, 64), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
+                       dtheta, delta, Nq, Nk);
+  else
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
+                       dtheta, delta, Nq, Nk);
   const long kblocks = (long)sg_cdiv(Nk, tk) * B;
   int zs = kblocks >= 1024 ? 1 : (int)((1024 + kblocks - 1) / kblocks);
   if (zs > 16) zs = 16;

@@ -280,10 +280,12 @@ def test_filterbank(dev, gen):
     close(dz, z.grad, tol=5e-5, name="dz")
 
 
-@pytest.mark.parametrize("Nq,Nk", [(128, 32), (384, 96), (640, 160), (300, 77)])
-def test_attention(dev, gen, Nq, Nk):
+# B = 2: the small-batch kernels (64 queries per workgroup, keys split over its four waves, partial states merged
+# through LDS); B = 260 with Nq = 1024: >= 1024 workgroups of 256 queries -> the one-lane-per-query kernels of the
+# full-batch step; (200, 300): more than four 64-key tiles per wave and ragged tails
+@pytest.mark.parametrize("B,Nq,Nk", [(2, 128, 32), (2, 384, 96), (2, 640, 160), (2, 300, 77), (3, 200, 300), (260, 1024, 72)])
+def test_attention(dev, gen, B, Nq, Nk):
     from scrabble_gan_amd import ops
-    B = 2
     th = (rnd(gen, B, Nq, 8) * 1.5).requires_grad_(True)
     ph = (rnd(gen, B, Nk, 8) * 1.5).requires_grad_(True)
     g = rnd(gen, B, Nk, 32).requires_grad_(True)

@@ -412,6 +412,17 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
         full = full_c;
         nsplit = best;
       }
+    } else {
+      // Whole rounds of 256, k = T / 256 tiles per CU, OCC of them resident at a time: when k is not a multiple of OCC the
+      // last k mod OCC tiles of every CU run under-occupied (10 tiles at 3 per CU: 3-3-3-1, the lone workgroup at ~70 %
+      // of the matrix rate).  Cutting those last tiles OCC ways keeps OCC workgroups resident to the end.
+      static const int occ_tail_env = getenv("SG_IGEMM_OCCTAIL") ? atoi(getenv("SG_IGEMM_OCCTAIL")) : 1;
+      const int k = tiles / CUS, r = k % OCC;
+      if (occ_tail_env && r != 0 && k >= OCC && KT_all >= 16 * OCC) {
+        const int full_c = (tiles - r * CUS) / n_tiles * n_tiles;
+        full = full_c;
+        nsplit = OCC;
+      }
     }
   }
   if (nsplit > 1 && !(a.flags & (SG_ACCUM | SG_PREZEROED))) {   // zero the rows the partial tiles add into (IDENT_OUT: one contiguous range)

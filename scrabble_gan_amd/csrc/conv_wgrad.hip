@@ -282,7 +282,9 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   for (long c = (1536 + combos - 1) / combos; c <= (3072 + combos - 1) / combos; ++c) {
     const long cc = c < 1 ? 1 : (c > max_chunks ? max_chunks : c);
     const long W = combos * cc;
-    const double loss = (double)((W + 255) / 256) * 256.0 / (double)W * (1.0 + 0.002 * cc);   // + epilogue cost per chunk
+    const long per_cu = (W + 255) / 256;
+    const double occ_pen = (per_cu % OCC) ? 1.01 : 1.0;     // a last round with fewer than OCC resident workgroups per CU
+    const double loss = (double)per_cu * 256.0 / (double)W * (1.0 + 0.002 * cc) * occ_pen;   // + epilogue cost per chunk
     if (loss < best) {
       best = loss;
       nchunks = cc;

@@ -162,3 +162,19 @@ def test_param_store_layout_on_cpu():
     assert S.grad.sum().item() == 128.0
     S.zero_grad()
     assert S.grad.abs().sum().item() == 0.0
+
+
+def test_step_scalars_sequence_protocol():
+    """train_step(..., sync='lazy') returns a StepScalars: the 16 values of data_utils.py:470-473 behind one deferred
+    host copy; it must behave as the 16-tuple the reference returns (len, index, iteration, str) and report alpha = 1."""
+    import torch
+    from scrabble_gan_amd.data_utils import StepScalars
+    vals = torch.arange(16, dtype=torch.float32) * 0.5
+    s = StepScalars(vals)
+    assert len(s) == 16
+    got = tuple(s)
+    assert got[10] == 1                                   # the reference returns the constant alpha, not a tensor value
+    assert [got[i] for i in range(16) if i != 10] == [0.5 * i for i in range(16) if i != 10]
+    assert s[3] == 1.5 and s[-1] == 7.5
+    assert repr(s) == repr(got)
+    assert ";".join(str(s[i]) for i in (6, 7, 8)) == "3.0;3.5;4.0"   # the summary writer's access pattern

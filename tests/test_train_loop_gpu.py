@@ -27,6 +27,15 @@ def test_main_synthetic_writes_summaries_and_checkpoints(dev, tmp_path, monkeypa
     for net in ("generator", "recognizer"):
         assert (tmp_path / "run" / "checkpoints" / net / "1" / "cktp-1.safetensors").exists()
     gin.clear_config()
+    # the inference script on the checkpoint just written (run_inference.py of the reference): two word lengths, 3 styles
+    from PIL import Image
+    from scrabble_gan_amd import run_inference as RI
+    png = tmp_path / "gen" / "words.png"
+    RI.main(["--weights", str(tmp_path / "run" / "checkpoints" / "generator" / "1" / "cktp-1"), "--words", "machine", "ab", "learn",
+             "--synthetic-style", "--count", "3", "--out", str(png)])
+    im = Image.open(png)
+    assert im.mode == "L" and im.size == (16 * 7, 9 * 32 + 8 * 2)      # 3 words x 3 styles, 2-pixel separators, widest word 7 chars
+    assert RI.encode("aZ") == [0, 51]
 
 
 def test_widest_bucket_and_bilstm_recognizer_step(dev):

@@ -328,6 +328,41 @@ class StepScalars:
 
 
 # ------------------------------------------------------------------------------------------------
+# Full training state: the reference saves G and R weights per epoch and cannot resume; this
+# writes EVERYTHING a restart needs -- parameters and BN moving statistics of all four networks, the optimizer slots and
+# step counters -- into one safetensors file (no pickle), plus the epoch / batch position.
+def save_training_state(path, generator, discriminator, recognizer, style_promoter, generator_optimizer, discriminator_optimizer,
+                        recognizer_optimizer, stylepromoter_optimizer, epoch_idx=0, batch_idx=0):
+    from safetensors.torch import save_file
+    out = {"position": torch.tensor([int(epoch_idx), int(batch_idx)], dtype=torch.int64)}
+    for tag, m, opt in (("G", generator, generator_optimizer), ("D", discriminator, discriminator_optimizer),
+                        ("R", recognizer, recognizer_optimizer), ("S", style_promoter, stylepromoter_optimizer)):
+        for k, v in m.store.export().items():
+            out["%s/%s" % (tag, k)] = v.contiguous()
+        for k, v in opt.flat_state(m.store).items():
+            out["%s.opt/%s" % (tag, k)] = v.detach().cpu().contiguous()
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    save_file(out, path + ".tmp")
+    os.replace(path + ".tmp", path)                       # a crash while writing never clobbers the previous state
+
+
+def load_training_state(path, generator, discriminator, recognizer, style_promoter, generator_optimizer, discriminator_optimizer,
+                        recognizer_optimizer, stylepromoter_optimizer):
+    """Restores what save_training_state wrote; -> (epoch_idx, batch_idx) of the save."""
+    from safetensors.torch import load_file
+    st = load_file(path)
+    for tag, m, opt in (("G", generator, generator_optimizer), ("D", discriminator, discriminator_optimizer),
+                        ("R", recognizer, recognizer_optimizer), ("S", style_promoter, stylepromoter_optimizer)):
+        pre, opre = tag + "/", tag + ".opt/"
+        m.store.load({k[len(pre):]: v for k, v in st.items() if k.startswith(pre)})
+        opt.load_flat_state(m.store, {k[len(opre):]: v for k, v in st.items() if k.startswith(opre)})
+    ops.weights_changed()
+    pos = st["position"].tolist()
+    return int(pos[0]), int(pos[1])
+
+
 SUMMARY_HEADER = ("disc_loss;disc_loss_real;disc_loss_fake;r_loss_real;r_loss_fake;r_loss_balanced;g_loss;g_lossT;g_lossS;"
                   "g_loss_final;alpha;r_loss_fake_std;g_loss_std;s_loss;s_loss_real;s_loss_fake\n")
 
@@ -335,9 +370,11 @@ SUMMARY_HEADER = ("disc_loss;disc_loss_real;disc_loss_fake;r_loss_real;r_loss_fa
 def train(dataset, generator, discriminator, recognizer, style_promoter, composite_gan, checkpoint, checkpoint_prefix,
           generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
           seed_labels, buffer_size, batch_size, epochs, model_path, latent_dim, gen_path, loss_fn, disc_iters,
-          apply_gradient_balance, random_words, bucket_size, char_vector, max_batches_per_epoch=None):
+          apply_gradient_balance, random_words, bucket_size, char_vector, max_batches_per_epoch=None, state_path=None):
     """Epoch/batch loop, 16-column ';' summaries and per-epoch G/R weight saves (data_utils.py:198-352).
-    The summary rows carry the ';' the reference drops between g_loss_std and s_loss (Appendix C-10)."""
+    The summary rows carry the ';' the reference drops between g_loss_std and s_loss (Appendix C-10).
+    `state_path` (not in the reference): full training state written there after every epoch and, when the file exists
+    at start, loaded first -- training continues with the epoch after the saved one."""
     generator_save_dir = os.path.join(checkpoint_prefix, 'generator/')
     recognizer_save_dir = os.path.join(checkpoint_prefix, 'recognizer/')
     os.makedirs(generator_save_dir, exist_ok=True)
@@ -351,11 +388,19 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
     print('no. batch_per_epoch:  ', batch_per_epoch)
     print('epoch size:           ', epochs)
     order = (6, 7, 8, 1, 0, 2, 3, 4, 5, 9, 10, 11, 12, 13, 14, 15)      # return tuple -> summary column order
-    with open(os.path.join(gen_path, "batch_summary.txt"), "w") as batch_summary, \
-            open(os.path.join(gen_path, "epoch_summary.txt"), "w") as epoch_summary:
-        epoch_summary.write(SUMMARY_HEADER)
-        batch_summary.write(SUMMARY_HEADER)
-        for epoch_idx in range(epochs):
+    first_epoch = 0
+    if state_path is not None and os.path.exists(state_path):
+        saved_epoch, _ = load_training_state(state_path, generator, discriminator, recognizer, style_promoter, generator_optimizer,
+                                             discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer)
+        first_epoch = saved_epoch + 1
+        print('resumed from %s: continuing with epoch %d' % (state_path, first_epoch + 1))
+    mode = "a" if first_epoch > 0 else "w"                   # a resumed run appends to the summaries of the first one
+    with open(os.path.join(gen_path, "batch_summary.txt"), mode) as batch_summary, \
+            open(os.path.join(gen_path, "epoch_summary.txt"), mode) as epoch_summary:
+        if first_epoch == 0:
+            epoch_summary.write(SUMMARY_HEADER)
+            batch_summary.write(SUMMARY_HEADER)
+        for epoch_idx in range(first_epoch, epochs):
             start = time.time()
             totals = [0.0] * 16
             pending = None          # the previous step's scalars: read back after the next step is queued, so the
@@ -380,6 +425,9 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
             print('Time for epoch {} is {} sec'.format(epoch_idx + 1, time.time() - start))
             generator.save_weights(os.path.join(generator_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
             recognizer.save_weights(os.path.join(recognizer_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
+            if state_path is not None:
+                save_training_state(state_path, generator, discriminator, recognizer, style_promoter, generator_optimizer,
+                                    discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, epoch_idx, batch_per_epoch)
 
 
 # ------------------------------------------------------------------------------------------------

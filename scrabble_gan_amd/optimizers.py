@@ -43,6 +43,17 @@ class Adam:
     def state_dict(self):
         return {"iterations": self.iterations, "slots": {str(i): (m.cpu(), v.cpu()) for i, (m, v) in enumerate(self._slots.values())}}
 
+    def flat_state(self, store):
+        """{name: tensor} of this optimizer's state for `store`'s flat buffer (full-state checkpoints)."""
+        m, v = self._slot(store.flat)
+        return {"m": m, "v": v, "iterations": torch.tensor([self.iterations], dtype=torch.int64)}
+
+    def load_flat_state(self, store, state):
+        m, v = self._slot(store.flat)
+        m.copy_(state["m"].to(m.device))
+        v.copy_(state["v"].to(v.device))
+        self.iterations = int(state["iterations"].reshape(-1)[0].item())
+
 
 class RMSprop:
     def __init__(self, learning_rate=0.001, rho=0.9, epsilon=1e-7):
@@ -59,6 +70,14 @@ class RMSprop:
     def apply_flat(self, store):
         self.iterations += 1
         ops.rmsprop_update(store.flat, store.grad, self._slot(store.flat), self.learning_rate, self.rho, self.epsilon)
+
+    def flat_state(self, store):
+        return {"ms": self._slot(store.flat), "iterations": torch.tensor([self.iterations], dtype=torch.int64)}
+
+    def load_flat_state(self, store, state):
+        ms = self._slot(store.flat)
+        ms.copy_(state["ms"].to(ms.device))
+        self.iterations = int(state["iterations"].reshape(-1)[0].item())
 
     def apply_gradients(self, grads_and_vars):
         self.iterations += 1

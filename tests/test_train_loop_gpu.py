@@ -109,3 +109,55 @@ def test_shared_sweeps_and_fused_passes_equal_the_reference_schedule(dev):
         tol = 5e-2 if n == "G" else 2e-4
         assert (da - db).abs().max().item() <= tol * scale, "%s gradients: %.3e vs scale %.3e" % (n, (da - db).abs().max().item(), scale)
         assert (wa - wb).abs().max().item() <= 5e-4, n
+
+
+def test_full_state_save_and_resume(dev, tmp_path):
+    """save_training_state / load_training_state (the reference cannot resume): three steps in one go against
+    two steps, save, rebuild every object from scratch, load, one more step -- same weights, BN statistics and Adam state."""
+    import random
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
+    B, L = 4, 3
+    images, labels, my_imgs = DU.synthetic_batch(B, L, seed=3)
+    words = DU.synthetic_random_words(10, 50, seed=3)
+
+    def build():
+        NA._model_counter[0] = 0
+        NA.configure(device=dev, seed=4)
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+        return G, D, R, S, NA.make_gan(G, D, R, S, vis_model=False), [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+
+    def steps(objs, first, n):
+        G, D, R, S, gan, opts = objs
+        for i in range(first, first + n):
+            random.seed(100 + i)                              # the fake-label draw of step i
+            torch.manual_seed(100 + i)
+            G.nl_gen.manual_seed(1000 + i); D.nl_gen.manual_seed(2000 + i); S.nl_gen.manual_seed(3000 + i)   # per-call kernel re-draws
+            DU.train_step(0, i, 9, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_imgs, B, 128, net_loss.hinge, 1, 0,
+                          words, 10, "", verbose=False)
+
+    a = build()
+    steps(a, 0, 3)
+    b = build()
+    steps(b, 0, 2)
+    path = str(tmp_path / "state" / "latest.safetensors")
+    DU.save_training_state(path, b[0], b[1], b[2], b[3], *b[5], epoch_idx=0, batch_idx=2)
+    c = build()                                               # fresh weights, fresh optimizers
+    assert DU.load_training_state(path, c[0], c[1], c[2], c[3], *c[5]) == (0, 2)
+    assert all(o.iterations == 2 for o in c[5])
+    steps(c, 2, 1)
+    for ma, mc, oa, oc in zip(a[:4], c[:4], a[5], c[5]):
+        assert oa.iterations == oc.iterations == 3
+        # Float-atomic summation order moves gradients in their last bits; Adam (beta_1 = 0) normalises every component to
+        # +-lr, so a component whose gradient is ~0 may step the other way: a handful of entries differ by up to 2 lr,
+        # the mean difference stays orders of magnitude below lr.  A state that was NOT restored moves every entry by O(lr).
+        diff = (ma.store.flat - mc.store.flat).abs()
+        assert diff.max().item() <= 1e-3 and diff.mean().item() <= 2e-5, (ma.name, diff.max().item(), diff.mean().item())
+        assert (ma.store.state - mc.store.state).abs().max().item() <= 1e-5, ma.name
+        for k in ("m", "v"):
+            sa, sc = oa.flat_state(ma.store)[k], oc.flat_state(mc.store)[k]
+            # (the last gradient and its running square: run-to-run noise of the float atomics, amplified where a ReLU /
+            #  max-pool decision sits on the edge -- the same 1e-3-of-max bar as the data-parallel comparison)
+            assert (sa - sc).abs().max().item() <= 5e-3 * sa.abs().max().item() + 1e-12, (ma.name, k, (sa - sc).abs().max().item(), sa.abs().max().item())

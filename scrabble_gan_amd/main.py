@@ -82,6 +82,8 @@ def main(argv=None):
     ap.add_argument("--gin", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs",
                                                   "scrabble_gan_mi355x.gin"))
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--resumable", action="store_true",
+                    help="write the full training state to <checkpoints>/state/latest.safetensors every epoch and resume from it when it exists")
     ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"], help="matrix-core operand type of the convolutions")
     ap.add_argument("--steps", type=int, default=None, help="cap batches per epoch")
     ap.add_argument("--epochs", type=int, default=None)
@@ -117,7 +119,8 @@ def main(argv=None):
     train(train_dataset, generator, discriminator, recognizer, style_promoter, gan, None, ckpt_path, generator_optimizer,
           discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, train_imgs, [None, labels], buf_size, batch_size,
           epochs, m_path, latent_dim, gen_path, loss_fn, disc_iters, apply_gradient_balance, random_words, bucket_size, char_vec,
-          max_batches_per_epoch=args.steps)
+          max_batches_per_epoch=args.steps,
+          state_path=os.path.join(ckpt_path, "state", "latest.safetensors") if args.resumable else None)
 
 
 if __name__ == "__main__":

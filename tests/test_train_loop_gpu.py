@@ -16,7 +16,7 @@ def test_main_synthetic_writes_summaries_and_checkpoints(dev, tmp_path, monkeypa
     base = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "scrabble_gan_mi355x.gin")).read()
     cfg.write_text(base + "\nio.base_path = '%s/'\nshared_specs.batch_size = 4\nshared_specs.num_gen = 4\n" % tmp_path)
     gin.clear_config()
-    M.main(["--gin", str(cfg), "--synthetic", "--steps", "3", "--epochs", "1"])
+    M.main(["--gin", str(cfg), "--synthetic", "--steps", "3", "--epochs", "1", "--resumable"])
     out = tmp_path / "run" / "output"
     rows = (out / "batch_summary.txt").read_text().strip().split("\n")
     assert rows[0].startswith("disc_loss;disc_loss_real") and len(rows) == 4
@@ -36,6 +36,13 @@ def test_main_synthetic_writes_summaries_and_checkpoints(dev, tmp_path, monkeypa
     im = Image.open(png)
     assert im.mode == "L" and im.size == (16 * 7, 9 * 32 + 8 * 2)      # 3 words x 3 styles, 2-pixel separators, widest word 7 chars
     assert RI.encode("aZ") == [0, 51]
+    # --resumable: the full state of epoch 1 is on disk; asking for 2 epochs now runs ONLY the second one
+    assert (tmp_path / "run" / "checkpoints" / "state" / "latest.safetensors").exists()
+    M.main(["--gin", str(cfg), "--synthetic", "--steps", "3", "--epochs", "2", "--resumable"])
+    assert len((out / "epoch_summary.txt").read_text().strip().split("\n")) == 3          # header + epoch 1 + epoch 2
+    assert len((out / "batch_summary.txt").read_text().strip().split("\n")) == 7          # header + 3 + 3 steps
+    assert (tmp_path / "run" / "checkpoints" / "generator" / "2" / "cktp-2.safetensors").exists()
+    gin.clear_config()
 
 
 def test_widest_bucket_and_bilstm_recognizer_step(dev):

@@ -63,6 +63,14 @@ int sg_conv2d_fwd_bf16(const float* x, const void* wp_fwd, const float* bias, co
 int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, const float* mask, float* dx,
                             int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* bf16 variants of the transposed convolution (w [kh,kw,Cout,Cin]): forward wp = pack(w, kh*kw, K = Cin, N = Cout,
+ * transpose = 0); data-grad wp = pack(w, kh*kw, K = Cout, N = Cin, transpose = 1).  SG_ERR_UNSUPPORTED for a stride /
+ * kernel combination with a tap-less parity class (1x1, stride 2) and for K % 8 != 0 or N <= 32: use the fp32 entry. */
+int sg_conv2d_transpose_fwd_bf16(const float* x, const void* wp, const float* bias, const float* bias2, float* y,
+                                 int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream);
+int sg_conv2d_transpose_bwd_data_bf16(const float* dy, const void* wp, const float* mask, float* dx,
+                                      int B, int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream);
+
 /* ---- layers.Conv2DTranspose(padding='same', strides=(sh,sw)) (resnet_ops.py:57,69) ------- */
 /* x [B,H,W,Cin] -> y [B,sh*H,sw*W,Cout]; k=3,s=2: y[2i+k] += x[i] w[k] cropped to 2n; bias everywhere */
 int sg_conv2d_transpose_fwd(const float* x, const float* w, const float* bias, const float* bias2, float* y,

@@ -399,3 +399,50 @@ extern "C" int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, cons
     for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
   return sg_launch_igemm_bf16(a, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// Conv2DTranspose(padding='same', strides (sh, sw)) with bf16 matrix-core operands: the same parity-class / tap-list
+// launches as the fp32 entry points (conv_igemm.hip), filter w [kh,kw,Cout,Cin] given as packed bf16 copies:
+//   forward  : wp = pack(w, taps, K = Cin,  N = Cout, transpose = 0)   (each tap is already [N = Cout][K = Cin])
+//   data-grad: wp = pack(w, taps, K = Cout, N = Cin,  transpose = 1)
+// ------------------------------------------------------------------------------------------
+static inline int floordiv_b(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+extern "C" int sg_conv2d_transpose_fwd_bf16(const float* x, const void* wp, const float* bias, const float* bias2, float* y, int B,
+                                            int H, int W, int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream) {
+  if (!x || !wp || !y || kh * kw > SG_MAX_TAPS || sh < 1 || sw < 1) return SG_ERR_ARG;
+  const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  for (int py = 0; py < sh; ++py)
+    for (int px = 0; px < sw; ++px) {
+      SgIgemmArgs a{};
+      a.a = x; a.w = (const float*)wp; a.out = y; a.bias = bias; a.bias2 = bias2;
+      a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+      a.Ho = sh * H; a.Wo = sw * W; a.N = Cout; a.o_sy = sh; a.o_sx = sw; a.o_oy = py; a.o_ox = px;
+      a.ldw = Cin; a.flags = flags; a.ntaps = 0;
+      for (int ky = 0; ky < kh; ++ky) {
+        if ((py + pbh - ky) % sh) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+          if ((px + pbw - kx) % sw) continue;
+          a.taps[a.ntaps++] = SgTap{floordiv_b(py + pbh - ky, sh), floordiv_b(px + pbw - kx, sw), (ky * kw + kx) * Cin * Cout};
+        }
+      }
+      if (a.ntaps == 0) return SG_ERR_UNSUPPORTED;      // a class that only writes its bias: the fp32 entry point handles it
+      const int rc = sg_launch_igemm_bf16(a, (hipStream_t)stream);
+      if (rc != SG_OK) return rc;
+    }
+  return SG_OK;
+}
+
+extern "C" int sg_conv2d_transpose_bwd_data_bf16(const float* dy, const void* wp, const float* mask, float* dx, int B, int H, int W,
+                                                 int Cin, int Cout, int kh, int kw, int sh, int sw, int flags, void* stream) {
+  if (!dy || !wp || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int pbh = (sh == 1) ? kh / 2 : 0, pbw = (sw == 1) ? kw / 2 : 0;
+  SgIgemmArgs a{};
+  a.a = dy; a.w = (const float*)wp; a.out = dx; a.mask = mask;
+  a.Bn = B; a.Ha = sh * H; a.Wa = sw * W; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = sh; a.a_sx = sw;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.ldw = Cout; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - pbh, kx - pbw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm_bf16(a, (hipStream_t)stream);
+}

@@ -159,6 +159,10 @@ def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
     if kind == "bwd_f32":            # fp32 [kh,kw,Cout,Cin]: the data-grad launch then reads it like a forward filter
         out = torch.empty(kh, kw, Cout, Cin, device=w.device, dtype=torch.float32)
         call("sg_transpose_filter", _p(w), _p(out), kh * kw, Cin, Cout, _stream())
+    elif kind == "t_fwd":            # Conv2DTranspose filter w [kh,kw,Co,Ci]: each tap already is [N = Co][K = Ci] -> convert only
+        call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, w.shape[3], w.shape[2], 0, _stream())
+    elif kind == "t_bwd":            # its data-grad reduces over Co: per tap [K = Co][N = Ci] -> [N = Ci][K = Co]
+        call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, w.shape[2], w.shape[3], 1, _stream())
     elif kind == "fwd":
         call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, Cin, Cout, 1, _stream())
     else:
@@ -236,8 +240,13 @@ def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, a
     if out is None:
         out = empty(B, sh * H, sw * W, Cout, like=x)
     with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_fwd", B, H, W, Cin, Cout, kh), (x, w, out)):
-        call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
-             _flags(accum=accum), _stream())
+        # bf16 mode: every parity class needs a tap (kernel >= stride), otherwise the fp32 entry point writes the bias-only classes
+        if _bf16_ok(Cin, Cout) and kh >= sh and kw >= sw:
+            call("sg_conv2d_transpose_fwd_bf16", _p(x), packed_filter(w, "t_fwd").data_ptr(), _p(bias), _p(bias2), _p(out), B, H, W,
+                 Cin, Cout, kh, kw, sh, sw, _flags(accum=accum), _stream())
+        else:
+            call("sg_conv2d_transpose_fwd", _p(x), _p(w), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+                 _flags(accum=accum), _stream())
     return out
 
 
@@ -250,8 +259,12 @@ def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=F
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
     with _timed("igemm", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
-        call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
-             _flags(accum=accum), _stream())
+        if _bf16_ok(Cout, Cin):
+            call("sg_conv2d_transpose_bwd_data_bf16", _p(dy), packed_filter(w, "t_bwd").data_ptr(), _p(mask), _p(out), B, H, W,
+                 Cin, Cout, kh, kw, sh, sw, _flags(accum=accum), _stream())
+        else:
+            call("sg_conv2d_transpose_bwd_data", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, sh, sw,
+                 _flags(accum=accum), _stream())
     return out
 
 

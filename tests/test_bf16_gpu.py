@@ -191,3 +191,22 @@ def test_bf16_kernels_full_size_on_bf16_representable_inputs(dev, bf16_mode, H, 
     y, dx, dw = res["bf16"]
     a, b, c = dot(y, dy), dot(x, dx), dot(w, dw)
     assert rel(a, b) < 2e-3 and rel(a, c) < 2e-3, (a, b, c)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [(2, 4, 8, 64, 64, 3, (2, 2)), (1, 8, 20, 256, 128, 3, (2, 2)), (2, 8, 16, 128, 64, 3, (2, 1)),
+                                                     (4, 4, 40, 512, 256, 3, (2, 2))])
+def test_conv2d_transpose_bf16(dev, gen, bf16_mode, B, H, W, Cin, Cout, k, stride):
+    """Conv2DTranspose forward / data-grad with bf16 operands (the generator's up path in config c3)."""
+    ops = bf16_mode
+    x = rnd(gen, B, H, W, Cin)
+    w = rnd(gen, k, k, Cout, Cin) / math.sqrt(k * k * Cin)
+    b = rnd(gen, Cout)
+    xg, wg, bg = g32(x, dev), g32(w, dev), g32(b, dev)
+    y = ops.conv2d_transpose_fwd(xg, wg, bg, stride=stride)
+    close(y, O.conv2d_transpose(r16(x), r16(w), b, stride), 5e-5, "convT fwd vs bf16-rounded-operand oracle")
+    close(y, O.conv2d_transpose(x, w, b, stride), 1e-2, "convT fwd vs exact oracle")
+    dy = rnd(gen, *y.shape)
+    xr = x.clone().requires_grad_(True)
+    O.conv2d_transpose(xr, r16(w), None, stride).backward(r16(dy))
+    dx = ops.conv2d_transpose_bwd_data(g32(dy, dev), wg, stride=stride, mask=xg)
+    close(dx, xr.grad * (x > 0), 5e-5, "convT dgrad (mask) vs bf16-rounded-operand oracle")

@@ -500,11 +500,18 @@ __global__ __launch_bounds__(256) void sg_thin_expand_kernel(const SgThinArgs p)
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + c);
   const bool relu_in = p.flags & SG_RELU_IN, accum = p.flags & SG_ACCUM, relu_out = p.flags & SG_RELU_OUT;
-  for (long e = gtid; e < M * cq; e += gsz) {
-    const long m = e / cq;
-    const int b = (int)(m / HW);
+  // cq divides the 256-thread block, so a thread keeps its channel group and walks pixels m0, m0 + step, ...: the pixel
+  // cursor (b, yg, xg) is decoded once and advanced without divisions
+  const long mstep = gsz / cq;
+  long m = gtid / cq;
+  int b = (int)(m / HW), yg, xg;
+  {
     const int rem = (int)(m - (long)b * HW);
-    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    yg = rem / p.Wg;
+    xg = rem - yg * p.Wg;
+  }
+  const int adv_b = (int)(mstep / HW), adv_r = (int)(mstep - (long)adv_b * HW), adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
+  for (; m < M; m += mstep) {
     float4 o = bv;
 #pragma unroll
     for (int t = 0; t < SG_MAX_TAPS; ++t) {
@@ -530,6 +537,13 @@ __global__ __launch_bounds__(256) void sg_thin_expand_kernel(const SgThinArgs p)
     }
     if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *reinterpret_cast<float4*>(op) = o;
+    xg += adv_x;
+    const int cx = xg >= p.Wg ? 1 : 0;
+    xg -= cx * p.Wg;
+    yg += adv_y + cx;
+    const int cy = yg >= p.Hg ? 1 : 0;
+    yg -= cy * p.Hg;
+    b += adv_b + cy;
   }
 }
 
@@ -544,12 +558,25 @@ __global__ __launch_bounds__(256) void sg_thin_contract_kernel(const SgThinArgs 
   const bool relu_in = p.flags & SG_RELU_IN, accum = p.flags & SG_ACCUM, tanh_out = p.flags & SG_TANH_OUT;
   const float bias = p.bias ? p.bias[0] : 0.f;
   const long Mpad = (M + 3) / 4 * 4;  // keep all 64 lanes in the shuffles
+  // pixel cursor advanced by pstride pixels per iteration (decoded once; a padding lane past M keeps computing on a
+  // clamped pixel 0 as before)
+  int cb = (int)(pix0 / HW), cy_, cx_;
+  {
+    const int rem = (int)(pix0 - (long)cb * HW);
+    cy_ = rem / p.Wg;
+    cx_ = rem - cy_ * p.Wg;
+  }
+  const int adv_b = (int)(pstride / HW), adv_r = (int)(pstride - (long)adv_b * HW), adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
   for (long m = pix0; m < Mpad; m += pstride) {
     const bool live = m < M;
-    const long mm = live ? m : 0;
-    const int b = (int)(mm / HW);
-    const int rem = (int)(mm - (long)b * HW);
-    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    const int b = live ? cb : 0, yg = live ? cy_ : 0, xg = live ? cx_ : 0;
+    cx_ += adv_x;
+    const int wx = cx_ >= p.Wg ? 1 : 0;
+    cx_ -= wx * p.Wg;
+    cy_ += adv_y + wx;
+    const int wy = cy_ >= p.Hg ? 1 : 0;
+    cy_ -= wy * p.Hg;
+    cb += adv_b + wy;
     float s = 0.f;
     for (int t = 0; t < p.ntaps; ++t) {
       const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;

@@ -338,10 +338,17 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the C-channel operand (bias gradient when it is dy)
-  for (long m = m_begin + pl; m < m_end; m += lanes) {
-    const int b = (int)(m / HW);
+  // pixel cursor (b, yg, xg), decoded once and advanced by `lanes` pixels per iteration: no (64-bit) division in the loop
+  long m = m_begin + pl;
+  int b = (int)(m / HW);
+  int yg, xg;
+  {
     const int rem = (int)(m - (long)b * HW);
-    const int yg = rem / p.Wg, xg = rem - yg * p.Wg;
+    yg = rem / p.Wg;
+    xg = rem - yg * p.Wg;
+  }
+  const int adv_b = lanes / HW, adv_r = lanes - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
+  for (; m < m_end; m += lanes) {
     float4 q = *reinterpret_cast<const float4*>(p.w + (size_t)m * p.C + 4 * cq);
     if (p.qscale) { const float sc = p.qscale[b]; q.x *= sc; q.y *= sc; q.z *= sc; q.w *= sc; }
     if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
@@ -356,6 +363,13 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
         acc[t].x += a * q.x; acc[t].y += a * q.y; acc[t].z += a * q.z; acc[t].w += a * q.w;
       }
     }
+    xg += adv_x;
+    const int cx = xg >= p.Wg ? 1 : 0;
+    xg -= cx * p.Wg;
+    yg += adv_y + cx;
+    const int cy = yg >= p.Hg ? 1 : 0;
+    yg -= cy * p.Hg;
+    b += adv_b + cy;
   }
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) {

@@ -338,38 +338,52 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the C-channel operand (bias gradient when it is dy)
-  // pixel cursor (b, yg, xg), decoded once and advanced by `lanes` pixels per iteration: no (64-bit) division in the loop
-  long m = m_begin + pl;
-  int b = (int)(m / HW);
-  int yg, xg;
-  {
-    const int rem = (int)(m - (long)b * HW);
-    yg = rem / p.Wg;
-    xg = rem - yg * p.Wg;
-  }
-  const int adv_b = lanes / HW, adv_r = lanes - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
-  for (; m < m_end; m += lanes) {
-    float4 q = *reinterpret_cast<const float4*>(p.w + (size_t)m * p.C + 4 * cq);
-    if (p.qscale) { const float sc = p.qscale[b]; q.x *= sc; q.y *= sc; q.z *= sc; q.w *= sc; }
-    if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
-    qsum.x += q.x; qsum.y += q.y; qsum.z += q.z; qsum.w += q.w;
+  // U pixels per thread and iteration (U independent 16-byte loads in flight: the sweep is latency-bound otherwise), each
+  // with its own pixel cursor (b, yg, xg), decoded once and advanced by U * lanes pixels without divisions
+  constexpr int U = 4;
+  int cb[U], cy[U], cx[U];
 #pragma unroll
-    for (int t = 0; t < SG_MAX_TAPS; ++t) {
-      if (t < p.ntaps) {
-        const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;
-        float a = 0.f;
-        if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
-        if (relu_in) a = fmaxf(a, 0.f);
-        acc[t].x += a * q.x; acc[t].y += a * q.y; acc[t].z += a * q.z; acc[t].w += a * q.w;
-      }
+  for (int j = 0; j < U; ++j) {
+    const long mj = m_begin + pl + (long)j * lanes;
+    cb[j] = (int)(mj / HW);
+    const int rem = (int)(mj - (long)cb[j] * HW);
+    cy[j] = rem / p.Wg;
+    cx[j] = rem - cy[j] * p.Wg;
+  }
+  const int step = U * lanes;
+  const int adv_b = step / HW, adv_r = step - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
+  for (long m = m_begin + pl; m < m_end; m += step) {
+    float4 q[U];
+    bool live[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long mj = m + (long)j * lanes;
+      live[j] = mj < m_end;
+      q[j] = live[j] ? *reinterpret_cast<const float4*>(p.w + (size_t)mj * p.C + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    xg += adv_x;
-    const int cx = xg >= p.Wg ? 1 : 0;
-    xg -= cx * p.Wg;
-    yg += adv_y + cx;
-    const int cy = yg >= p.Hg ? 1 : 0;
-    yg -= cy * p.Hg;
-    b += adv_b + cy;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (p.qscale) { const float sc = live[j] ? p.qscale[cb[j]] : 0.f; q[j].x *= sc; q[j].y *= sc; q[j].z *= sc; q[j].w *= sc; }
+      if (relu_q) { q[j].x = fmaxf(q[j].x, 0.f); q[j].y = fmaxf(q[j].y, 0.f); q[j].z = fmaxf(q[j].z, 0.f); q[j].w = fmaxf(q[j].w, 0.f); }
+      qsum.x += q[j].x; qsum.y += q[j].y; qsum.z += q[j].z; qsum.w += q[j].w;
+#pragma unroll
+      for (int t = 0; t < SG_MAX_TAPS; ++t) {
+        if (t < p.ntaps) {
+          const int iy = cy[j] + p.taps[t].dy, ix = cx[j] + p.taps[t].dx;
+          float a = 0.f;
+          if (live[j] && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)cb[j] * p.Ha + iy) * p.Wa + ix];
+          if (relu_in) a = fmaxf(a, 0.f);
+          acc[t].x += a * q[j].x; acc[t].y += a * q[j].y; acc[t].z += a * q[j].z; acc[t].w += a * q[j].w;
+        }
+      }
+      cx[j] += adv_x;
+      const int wx = cx[j] >= p.Wg ? 1 : 0;
+      cx[j] -= wx * p.Wg;
+      cy[j] += adv_y + wx;
+      const int wy = cy[j] >= p.Hg ? 1 : 0;
+      cy[j] -= wy * p.Hg;
+      cb[j] += adv_b + wy;
+    }
   }
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) {

@@ -178,3 +178,21 @@ def test_step_scalars_sequence_protocol():
     assert s[3] == 1.5 and s[-1] == 7.5
     assert repr(s) == repr(got)
     assert ";".join(str(s[i]) for i in (6, 7, 8)) == "3.0;3.5;4.0"   # the summary writer's access pattern
+
+
+def test_cli_entry_points_parse_on_cpu():
+    """bench.py, the trainer and the inference script must at least import and parse their arguments without a GPU
+    (the driver launches them by path / module name)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmd in ([sys.executable, os.path.join(root, "bench.py"), "--help"],
+                [sys.executable, "-m", "scrabble_gan_amd.main", "--help"],
+                [sys.executable, "-m", "scrabble_gan_amd.run_inference", "--help"]):
+        r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (cmd, r.stderr[-500:])
+        assert "usage" in r.stdout.lower()
+    for flag in ("--gpus", "--steps", "--warmup", "--conv-dtype", "--bucketed"):
+        assert flag in subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], cwd=root, capture_output=True,
+                                      text=True, timeout=300).stdout

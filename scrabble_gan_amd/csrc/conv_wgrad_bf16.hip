@@ -20,7 +20,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // pixels of a k-tile lie in one sample)
 template <int QSCALE>
 __global__ __launch_bounds__(256, 3) void sg_wgrad_bf16_kernel(const SgWgradArgs p) {
-  constexpr int BC = 128, BN = 128, WM = 2, WN = 2, BK = 32, LDK = 40, NT = 256;
+  constexpr int BC = 128, BN = 128, WM = 2, WN = 2, BK = 32, LDK = 40;
   constexpr int TM = BC / WM / 32, TN = BN / WN / 32;
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BC * LDK + 2 * BN * LDK];
   unsigned short* Ps = smem;

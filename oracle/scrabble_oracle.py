@@ -131,11 +131,15 @@ def filter_bank_seed(z0: Tensor, y: Tensor, table: Tensor) -> Tensor:
 
 
 def conditional_batch_norm(x: Tensor, z: Tensor, w_gamma: Tensor, w_beta: Tensor,
-                           stats: Optional[dict] = None) -> Tensor:
+                           stats: Optional[dict] = None, moving: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """ConditionalBatchNorm.call (resnet_ops.py:13-28): BN without affine, then per-sample
-    gamma=Dense(z), beta=Dense(z) (gamma is NOT 1+gamma)."""
-    x_hat, mean, var = batch_norm_train(x)
-    if stats is not None:
+    gamma=Dense(z), beta=Dense(z) (gamma is NOT 1+gamma).  `moving` = (moving_mean, moving_variance)
+    selects inference mode (`training=False`, data_utils.py:505-507): normalise with the moving statistics."""
+    if moving is not None:
+        x_hat = (x - moving[0]) * torch.rsqrt(moving[1] + BN_EPS)
+    else:
+        x_hat, mean, var = batch_norm_train(x)
+    if stats is not None and moving is None:
         stats["mean"], stats["var"], stats["count"] = mean.detach(), var.detach(), x.numel() // x.shape[-1]
     gamma = (z @ w_gamma).reshape(-1, 1, 1, x.shape[-1])
     beta = (z @ w_beta).reshape(-1, 1, 1, x.shape[-1])
@@ -170,17 +174,19 @@ def resnet_block_down(x: Tensor, p: Dict[str, Tensor], pre: str, is_last: bool) 
 
 
 def resnet_block_up(x: Tensor, z: Tensor, p: Dict[str, Tensor], pre: str, is_last: bool,
-                    bn_stats: Optional[dict] = None) -> Tensor:
-    """ResNetBlockUp.call (resnet_ops.py:46-74)."""
+                    bn_stats: Optional[dict] = None, training: bool = True) -> Tensor:
+    """ResNetBlockUp.call (resnet_ops.py:46-74).  training=False: both ConditionalBatchNorms use their moving statistics."""
     stride = (2, 1) if is_last else (2, 2)                                     # :54
     s1 = {} if bn_stats is not None else None
     s2 = {} if bn_stats is not None else None
-    net = torch.relu(conditional_batch_norm(x, z, p[pre + ".cbn1.gamma.w"], p[pre + ".cbn1.beta.w"], s1))
+    m1 = None if training else (p[pre + ".cbn1.mm"], p[pre + ".cbn1.mv"])
+    m2 = None if training else (p[pre + ".cbn2.mm"], p[pre + ".cbn2.mv"])
+    net = torch.relu(conditional_batch_norm(x, z, p[pre + ".cbn1.gamma.w"], p[pre + ".cbn1.beta.w"], s1, m1))
     net = conv2d_transpose(net, p[pre + ".convT.w"], p[pre + ".convT.b"], stride)
-    net = torch.relu(conditional_batch_norm(net, z, p[pre + ".cbn2.gamma.w"], p[pre + ".cbn2.beta.w"], s2))
+    net = torch.relu(conditional_batch_norm(net, z, p[pre + ".cbn2.gamma.w"], p[pre + ".cbn2.beta.w"], s2, m2))
     net = conv2d(net, p[pre + ".conv.w"], p[pre + ".conv.b"])
     sc = conv2d_transpose(x, p[pre + ".short.w"], p[pre + ".short.b"], stride)
-    if bn_stats is not None:
+    if bn_stats is not None and training:
         bn_stats[pre + ".cbn1"], bn_stats[pre + ".cbn2"] = s1, s2
     return net + sc
 
@@ -211,8 +217,11 @@ def discriminator(x: Tensor, p: Dict[str, Tensor], nl: Optional[Dict[str, Tensor
 
 def generator(style: Tensor, y: Tensor, p: Dict[str, Tensor], nl_style: Dict[str, Tensor],
               nl_up: Optional[Dict[str, Tensor]], attn_blocks: str = "B3",
-              bn_stats: Optional[dict] = None) -> Tensor:
-    """make_generator forward in training mode (net_architecture.py:182-296)."""
+              bn_stats: Optional[dict] = None, training: bool = True) -> Tensor:
+    """make_generator forward (net_architecture.py:182-296).  training=True: batch statistics in the seven
+    BatchNorms (and `bn_stats` collects them for the moving-average update); training=False =
+    `generator([style, labels], training=False)` of generate_and_save_images (data_utils.py:505-507): every
+    BatchNormalization normalises with its moving mean / variance (Appendix A-4)."""
     if style.dim() == 3:                                    # Appendix C-8
         style = style.unsqueeze(-1)
     h = disc_trunk(style, p, nl_style, "B_style1", block_fmt="B_style{}")     # :241-250
@@ -221,10 +230,14 @@ def generator(style: Tensor, y: Tensor, p: Dict[str, Tensor], nl_style: Dict[str
     net = filter_bank_seed(z0, y, p["filter_bank"])                            # :265-271
     for i, zi in enumerate((z1, z2, z3)):
         name = "B{}".format(i + 1)
-        net = resnet_block_up(net, zi, p, name, is_last=(i == 2), bn_stats=bn_stats)   # :274-277
+        net = resnet_block_up(net, zi, p, name, is_last=(i == 2), bn_stats=bn_stats, training=training)   # :274-277
         if name in attn_blocks:                                                # :278-279
             net = nonlocal_block(net, nl_up["theta"], nl_up["phi"], nl_up["g"], nl_up["o"],
                                  p["NL_" + name + ".sigma"])
+    if not training:
+        x_hat = (net - p["bn.mm"]) * torch.rsqrt(p["bn.mv"] + BN_EPS)
+        net = torch.relu(x_hat * p["bn.gamma"] + p["bn.beta"])
+        return torch.tanh(conv2d(net, p["final.w"], p["final.b"]))
     x_hat, mean, var = batch_norm_train(net)                                   # :281
     if bn_stats is not None:
         bn_stats["bn"] = {"mean": mean.detach(), "var": var.detach(), "count": net.numel() // net.shape[-1]}

@@ -1,0 +1,67 @@
+"""A well-conditioned train_step problem for the composed-step parity tests (test infrastructure; imports the oracle).
+
+Why a special fixture: with gradient balancing (data_utils.py:476-490 of the reference) G's upstream contains
+d std(g_loss)/d g_b = (g_b - mean)/(B std) -- the NORMALISED deviations of the per-sample generator losses.  An
+untrained D/S maps all fake images to almost the same logit (std/|mean| ~ 5e-3 with 0.1-sized random biases, B = 2),
+so fp32 rounding of the logits is amplified by |logit|/std in G's gradient -- for the fp32 evaluation of the ORACLE just
+as for the kernels.  Here the fake images are made to differ (style images with different mean levels, an amplified
+z = Dense(GAP(.))), D/S get small biases (the reference initialises them to zero) and a scaled final Dense so that the
+logits are O(1) with std ~ |mean|: the hinge kinks are exercised and std(g_loss) is O(1).
+
+`calibrate()` evaluates the oracle in fp64 and in fp32 on the same problem: |fp32 - fp64| per tensor is the yardstick the
+kernels are held to (tests/test_nets_gpu.py::test_train_step)."""
+import torch
+
+from oracle import scrabble_oracle as O
+
+NL_NAMES = ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")
+
+
+def make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=300.0, z_scale=30.0):
+    gen = torch.Generator().manual_seed(seed)
+    dt = torch.float64
+    P = {"G": O.init_generator(gen, dt), "D": O.init_discriminator(gen, dt), "S": O.init_discriminator(gen, dt),
+         "R": O.init_recognizer(gen, dt)}
+    for n, W in P.items():
+        for k, v in W.items():
+            if k.endswith(".sigma"):
+                W[k] = torch.tensor(0.3, dtype=dt)
+            elif k.endswith(".b") or k.endswith(".beta"):
+                W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * (0.01 if n in ("D", "S") else 0.1)
+            elif k.endswith(".gamma"):
+                W[k] = 1 + torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
+            elif k.endswith(".mm"):
+                W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
+            elif k.endswith(".mv"):
+                W[k] = 1 + torch.rand(v.shape, generator=gen, dtype=dt) * 0.2
+    P["D"]["dense.w"] = P["D"]["dense.w"] * logit_scale
+    P["S"]["dense.w"] = P["S"]["dense.w"] * logit_scale
+    P["G"]["zdense.w"] = P["G"]["zdense.w"] * z_scale
+    images = torch.rand(B, 32, 16 * L_r, 1, generator=gen, dtype=dt) * 2 - 1
+    noise = torch.rand(B, 32, style_w, 1, generator=gen, dtype=dt) * 2 - 1
+    style = (0.3 * noise + torch.linspace(-1, 1, B, dtype=dt).view(B, 1, 1, 1)).clamp(-1, 1)
+    labels = torch.randint(0, 52, (B, L_r), generator=gen)
+    fake = torch.randint(0, 52, (B, L_f), generator=gen)
+    nl = {n: O.init_nonlocal(64, gen) for n in NL_NAMES}
+    return dict(P=P, images=images, style=style, labels=labels, fake=fake, nl=nl, B=B, L_r=L_r, L_f=L_f)
+
+
+def run_oracle(pb, dtype, loss_name="hinge", balance=False):
+    """-> (16 scalars, {net: {name: grad}}, {net: {name: post-update weight}}, fake images); pb is not modified."""
+    cast = lambda t: t.to(dtype) if t.is_floating_point() else t
+    P = {n: {k: cast(v.clone()) for k, v in W.items()} for n, W in pb["P"].items()}
+    nl = {n: {k: cast(v) for k, v in d.items()} for n, d in pb["nl"].items()}
+    opt = {"G": {}, "D": {}, "R": {}, "S": {}}
+    loss = O.hinge if loss_name == "hinge" else O.not_saturating
+    scalars, grads, x_f = O.train_step(cast(pb["images"]), pb["labels"], cast(pb["style"]), pb["fake"], P["G"], P["D"], P["S"], P["R"],
+                                       nl, opt, loss_fn=loss, apply_gradient_balance=balance)
+    return scalars, grads, P, x_f
+
+
+def calibrate(pb, loss_name="hinge", balance=False):
+    """fp64 reference + the per-tensor deviation of the oracle's own fp32 evaluation from it."""
+    s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance)
+    s32, g32, w32, x32 = run_oracle(pb, torch.float32, loss_name, balance)
+    err32 = {n: {k: (g32[n][k].double() - v).abs().max().item() for k, v in g64[n].items()} for n in g64}
+    serr32 = [abs(a - b) for a, b in zip(s32, s64)]
+    return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item())

@@ -1,0 +1,109 @@
+"""BASELINE.json configs beyond the fixed-shape fp32 headline, each with a `-m gpu` case at B >= 8:
+
+  f1  generator([style, labels], training=False): BatchNorm moving statistics (data_utils.py:505-507), L in {2, 23};
+  c4  a variable-width (bucketed) train_step with L_r != L_f and full-width style images, bucket_size 23;
+  c3  a bs-256 train_step with bf16 matrix-core convolutions.
+
+f1 and c4 are held to the fp64 oracle (c4 with the calibrated bound of test_nets_gpu.py::test_train_step).  c3 at bs 256
+is beyond what the CPU oracle evaluates in minutes: the bf16 KERNELS meet the oracle at the real launch geometry in
+tests/test_fullsize_gpu.py and tests/test_bf16_gpu.py; here the whole bs-256 step in bf16 mode must track the
+(oracle-checked) fp32-mode step on identical weights and inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
+from tests.test_nets_gpu import check_step_against_calibrated_oracle, close, nl_pair, perturb  # noqa: E402
+
+
+@pytest.fixture()
+def NA(dev):
+    from scrabble_gan_amd import net_architecture as NA_
+    NA_.configure(device=dev, seed=3)
+    return NA_
+
+
+@pytest.mark.parametrize("L,style_w", [(2, 32), (23, 160)])
+def test_generator_inference_matches_oracle(NA, dev, L, style_w):
+    """G([style, y], training=False) (generate_and_save_images, data_utils.py:505-507): all seven BatchNorms normalise
+    with their MOVING mean / variance (perturbed here so they differ from any batch statistic).  fp32 kernels vs the
+    fp64 oracle: 1e-4 of max|ref| (= of 1, tanh output)."""
+    gen = torch.Generator().manual_seed(70 + L)
+    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+    P = perturb(G, gen)
+    B = 3
+    style = torch.rand(B, 32, style_w, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    y = torch.randint(0, 52, (B, L), generator=gen)
+    nls_o, nls_g = nl_pair(64, gen, dev)
+    nlu_o, nlu_g = nl_pair(64, gen, dev)
+    with torch.no_grad():
+        ref = O.generator(style, y, P, nls_o, nlu_o, training=False)
+        ref_train = O.generator(style, y, P, nls_o, nlu_o, training=True)
+    assert (ref - ref_train).abs().max().item() > 1e-2          # the two modes really differ on this problem
+    before = {k: G.store.p[k].clone() for k in G.store.names if k.endswith((".mm", ".mv"))}
+    img, _ = G.forward(style.float().to(dev), y.int().to(dev), nls_g, nlu_g, training=False)
+    assert tuple(img.shape) == (B, 32, 16 * L, 1)
+    close(img, ref, 1e-4, "inference image L=%d" % L)
+    for k, v in before.items():                                 # inference does not touch the moving statistics
+        assert torch.equal(G.store.p[k], v), k
+    # the Keras-style call the reference's caller makes
+    G.nl_gen.manual_seed(5)
+    a = G([style.float().numpy(), y.numpy().astype(np.int32)], training=False)
+    assert tuple(a.shape) == (B, 32, 16 * L, 1) and a.abs().max().item() <= 1.0
+
+
+def test_c4_bucketed_step_against_oracle(NA, dev):
+    """Config c4 (variable width): one train_step with real words of L_r = 5, fakes of L_f = 4 (bucket_size 23) and
+    full-width 32x160 style images at B = 8 -- three different widths, so every reference call is its own pass -- against
+    the fp64 oracle with the calibrated bound (hinge, no balancing: the c4 setting)."""
+    from tests import step_fixture as F
+    pb = F.make_problem(B=8, L_r=5, L_f=4, style_w=160, seed=23, logit_scale=70.0)
+    check_step_against_calibrated_oracle(NA, dev, pb, "hinge", False, "c4_Lr5_Lf4", bucket_size=23)
+
+
+def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
+    """Config c3: global batch 256, L_r = L_f = 10, bf16 matrix-core convolutions (fp32 accumulation), against the same
+    step in fp32 mode (same weights, inputs and NonLocalBlock kernels).  Tolerances = bf16 operand rounding: 16 scalars
+    within 3e-2 * max(1, |fp32|); every network's flat gradient has cosine > 0.995 with the fp32 one (G: > 0.97, its
+    gradient crosses the data-grad sweeps of D, S and R); fake images within 2e-2."""
+    from scrabble_gan_amd import data_utils as DU, net_loss, nn, ops, optimizers
+    B, L = 256, 10
+    images, labels, my_imgs = DU.synthetic_batch(B, L, seed=3)
+    words = DU.synthetic_random_words(10, 300, seed=3)
+    fake = np.array(words[L - 1][:B], np.int32)
+    res = {}
+    try:
+        for mode in ("f32", "bf16"):
+            ops.set_conv_dtype(mode)
+            NA._model_counter[0] = 0                       # identical initial weights in both runs
+            G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+            D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+            R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+            S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+            gan = NA.make_gan(G, D, R, S, vis_model=False)
+            for m in (G, D, S):
+                for k in m.store.names:
+                    if k.endswith(".sigma"):
+                        m.store.p[k].fill_(0.25)
+            g2 = torch.Generator().manual_seed(5)
+            nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
+                  for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+            x_f = G.forward(torch.from_numpy(my_imgs).to(dev), torch.from_numpy(fake).to(dev), nl["G.style"], nl["G.up"], training=False)[0]
+            opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+            out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_imgs, B, 128,
+                                net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake, nl=nl, verbose=False)
+            res[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}, x_f)
+            del G, D, R, S, gan
+    finally:
+        ops.set_conv_dtype("f32")
+    s32, g32_, x32 = res["f32"]
+    s16, g16, x16 = res["bf16"]
+    assert np.all(np.isfinite(s16))
+    assert np.all(np.abs(s16 - s32) <= 3e-2 * np.maximum(1.0, np.abs(s32))), (s16, s32)
+    assert (x16 - x32).abs().max().item() <= 2e-2
+    for n in ("D", "R", "S", "G"):
+        a, b = g32_[n].double(), g16[n].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > (0.97 if n == "G" else 0.995), "%s: cosine %.5f" % (n, cos)

@@ -82,3 +82,133 @@ def test_split_k_matches_single_pass(dev):
     dfull = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
     dpart = ops.conv2d_bwd_data(dy[:8].contiguous(), w, (H, W), mask=x[:8].contiguous())
     assert (dpart - dfull[:8]).abs().max().item() <= 2e-5 * dfull.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Oracle slices at the REAL launch geometry: the checks above compare the kernels with each
+# other; these put the headline launch path -- full_tiles >= 768, the XCD remap, the CU-quantum tail split, the
+# weight-grad's pixel chunking at B = 128..384 -- against the CPU oracle.  Samples of a convolution are independent,
+# so for y / dx the oracle evaluates only the first and last two samples of the batch (the tail tiles live at the
+# end); dW sums over the whole batch, so there the oracle runs the full batch on the two cheapest full-geometry layers.
+# Tolerances (max|got-ref| <= tol * max|ref|): fp32 kernels vs the fp64 oracle 2e-5 for y / dx, 1e-4 for dW (sums of up
+# to 82k products with float-atomic partial sums); bf16 mode vs the oracle on bf16-rounded operands 5e-5 / 1e-4.
+# ------------------------------------------------------------------------------------------------------------------
+import math  # noqa: E402
+
+from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
+
+GEOM = [  # B, H, W, Cin, Cout, k   (the fused-pass batch sizes of profiles/r01e_shapes_bs128.txt)
+    (128, 16, 80, 512, 512, 3), (384, 16, 80, 512, 512, 3), (256, 8, 40, 512, 1024, 3), (128, 8, 40, 1024, 1024, 3),
+    (384, 8, 40, 1024, 1024, 3), (256, 4, 20, 1024, 1024, 3), (384, 32, 160, 64, 64, 3), (256, 16, 80, 64, 512, 3),
+    (384, 8, 40, 512, 1024, 1),
+]
+
+
+def _edge(t, n=2):
+    return torch.cat([t[:n], t[-n:]], 0).double().cpu()
+
+
+def _close(got, ref, tol, name):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item() + 1e-30
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.fixture(params=["f32", "bf16"])
+def conv_mode(request):
+    from scrabble_gan_amd import ops
+    ops.set_conv_dtype(request.param)
+    yield request.param
+    ops.set_conv_dtype("f32")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", GEOM)
+def test_conv_fwd_dgrad_vs_oracle_at_launch_geometry(dev, conv_mode, B, H, W, Cin, Cout, k):
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B + H * W + Cin + k)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(k, k, Cin, Cout, device=dev, generator=g) / math.sqrt(k * k * Cin)
+    b = torch.randn(Cout, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    rq = _r16 if conv_mode == "bf16" else (lambda t: t)
+    y = ops.conv2d_fwd(x, w, b, relu_in=True)
+    dx = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+    xe, we, be, dye = _edge(x), w.double().cpu(), b.double().cpu(), _edge(dy)
+    _close(_edge(y), O.conv2d(rq(torch.relu(xe)), rq(we), be), 5e-5 if conv_mode == "bf16" else 2e-5, "y (first/last 2 samples)")
+    xr = xe.clone().requires_grad_(True)
+    O.conv2d(xr, rq(we), None).backward(rq(dye))
+    _close(_edge(dx), xr.grad * (xe > 0), 5e-5 if conv_mode == "bf16" else 2e-5, "dx (first/last 2 samples)")
+
+
+def _oracle_dw(x, dy, k, chunk=32):
+    """fp64 weight gradient of the SAME conv over the whole batch, accumulated chunk by chunk."""
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    tot = torch.zeros(k, k, Cin, Cout, dtype=torch.float64)
+    for lo in range(0, x.shape[0], chunk):
+        w = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        O.conv2d(x[lo:lo + chunk], w, None).backward(dy[lo:lo + chunk])
+        tot += w.grad
+    return tot
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,scaled", [(128, 4, 20, 1024, 1024, 3, False), (256, 4, 20, 1024, 1024, 3, True),
+                                                      (256, 8, 40, 512, 1024, 1, True), (128, 8, 40, 512, 1024, 1, False)])
+def test_conv_wgrad_vs_oracle_at_launch_geometry(dev, conv_mode, B, H, W, Cin, Cout, k, scaled):
+    """Whole-tensor dW (and the fused bias gradient) of the full batch: pixel chunking, the per-sample factors of the
+    shared backward sweep (`scaled`) and the float-atomic partial sums all take part."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B + H + Cin + k)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    sc = (torch.rand(B, device=dev, generator=g) * 2 - 0.5) if scaled else None
+    dw = torch.zeros(k, k, Cin, Cout, device=dev)
+    db = torch.zeros(Cout, device=dev)
+    ops.conv2d_bwd_weight(x, dy, dw, relu_in=True, db=db, sample_scale=sc)
+    dys32 = dy if sc is None else dy * sc.view(B, 1, 1, 1)            # the fp32 product the bf16 kernel rounds
+    xr = torch.relu(x).cpu()
+    if conv_mode == "bf16":
+        ref = _oracle_dw(_r16(xr), _r16(dys32.cpu()), k)
+    else:
+        dys = dy.double().cpu() if sc is None else dy.double().cpu() * sc.double().cpu().view(B, 1, 1, 1)
+        ref = _oracle_dw(xr.double(), dys, k)
+    _close(dw, ref, 1e-4, "dW (whole tensor, whole batch)")
+    _close(db, dys32.double().cpu().sum(dim=(0, 1, 2)), 5e-5, "fused bias gradient")
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,k,stride", [(4, 40, 512, 256, 3, (2, 2)), (8, 80, 256, 128, 3, (2, 2)),
+                                                 (16, 160, 128, 64, 3, (2, 1)), (4, 40, 512, 256, 1, (2, 2))])
+def test_conv_transpose_vs_oracle_at_launch_geometry(dev, conv_mode, H, W, Cin, Cout, k, stride):
+    """The generator's three Conv2DTranspose layers (+ a 1x1 stride-2 shortcut) at bs 128: y / dx on the first and
+    last two samples; dW of the whole batch on the cheapest layer."""
+    from scrabble_gan_amd import ops
+    B = 128
+    g = torch.Generator(device=dev).manual_seed(H + Cin + k)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(k, k, Cout, Cin, device=dev, generator=g) / math.sqrt(k * k * Cin)
+    b = torch.randn(Cout, device=dev, generator=g)
+    dy = torch.randn(B, stride[0] * H, stride[1] * W, Cout, device=dev, generator=g)
+    bf16 = conv_mode == "bf16" and k == 3         # the 1x1 stride-2 shortcuts keep the fp32 kernels (DESIGN 3b)
+    rq = _r16 if bf16 else (lambda t: t)
+    tol = 5e-5 if bf16 else 2e-5
+    y = ops.conv2d_transpose_fwd(x, w, b, stride=stride)
+    dx = ops.conv2d_transpose_bwd_data(dy, w, stride=stride)
+    xe, we, be, dye = _edge(x), w.double().cpu(), b.double().cpu(), _edge(dy)
+    _close(_edge(y), O.conv2d_transpose(rq(xe), rq(we), be, stride), tol, "convT y")
+    xr = xe.clone().requires_grad_(True)
+    O.conv2d_transpose(xr, rq(we), None, stride).backward(rq(dye))
+    _close(_edge(dx), xr.grad, tol, "convT dx")
+    if (H, k) in ((4, 3), (4, 1)):
+        dw = torch.zeros_like(w)
+        ops.conv2d_transpose_bwd_weight(x, dy, dw, stride=stride)
+        tot = torch.zeros(k, k, Cout, Cin, dtype=torch.float64)
+        xc, dyc = x.double().cpu(), dy.double().cpu()
+        for lo in range(0, B, 32):
+            wz = torch.zeros(k, k, Cout, Cin, dtype=torch.float64, requires_grad=True)
+            O.conv2d_transpose(xc[lo:lo + 32], wz, None, stride).backward(dyc[lo:lo + 32])
+            tot += wz.grad
+        _close(dw, tot, 1e-4, "convT dW (whole batch)")

@@ -214,3 +214,27 @@ def test_parameter_counts():
     assert n(O.init_discriminator(g(0), torch.float32)) == 37_336_385
     assert n(O.init_recognizer(g(0), torch.float32)) == 5_578_037
     assert abs(n(O.init_generator(g(0), torch.float32)) / 1e6 - 53.68) < 0.01
+
+
+def test_generator_inference_mode_uses_moving_statistics():
+    """training=False (data_utils.py:505-507): with the moving statistics of every BatchNorm set to the batch statistics of
+    a training-mode pass (biased variance, what the normalisation itself uses) the two modes give the same image; with
+    the Keras initial values (mean 0, variance 1) they do not."""
+    gen = g(5)
+    P = O.init_generator(gen)
+    for k in P:
+        if k.endswith(".beta.w") or k.endswith(".gamma.w"):
+            P[k] = P[k] * 1.0
+    style = torch.rand(2, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    y = torch.randint(0, 52, (2, 2), generator=gen)
+    nl_s, nl_u = O.init_nonlocal(64, gen), O.init_nonlocal(64, gen)
+    stats = {}
+    with torch.no_grad():
+        train = O.generator(style, y, P, nl_s, nl_u, bn_stats=stats)
+        cold = O.generator(style, y, P, nl_s, nl_u, training=False)
+        for pre, st in stats.items():
+            P[pre + ".mm"], P[pre + ".mv"] = st["mean"], st["var"]
+        warm = O.generator(style, y, P, nl_s, nl_u, training=False)
+    assert (train - cold).abs().max().item() > 1e-3
+    assert (train - warm).abs().max().item() < 1e-12
+    assert set(stats) == {"B1.cbn1", "B1.cbn2", "B2.cbn1", "B2.cbn2", "B3.cbn1", "B3.cbn2", "bn"}

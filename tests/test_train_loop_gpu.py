@@ -118,6 +118,59 @@ def test_shared_sweeps_and_fused_passes_equal_the_reference_schedule(dev):
         assert (wa - wb).abs().max().item() <= 5e-4, n
 
 
+def test_schedules_agree_at_headline_tile_geometry(dev):
+    """The same equivalence at a bs-128-like TILE geometry: B = 32 words of L = 10 (32x160 crops, the fused
+    passes carry 64 / 96 samples -> 2 560+ output tiles per large conv launch: full rounds, the XCD remap AND the
+    reduction-split tail are all active, nothing is forced through sg_debug_set_splitk).  Default schedule (fused passes,
+    shared sweeps) vs fuse_passes=False / share_backward=False, hinge, no balancing, well-conditioned logits (D/S Dense
+    scaled as in tests/step_fixture.py).  fp32 summation order is all that differs: scalars 1e-5, gradients of D / R / S
+    1e-4 and of G 1e-3 of the network's largest gradient."""
+    import numpy as np
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, nn, optimizers
+    B, L = 32, 10
+    images, labels, style = DU.synthetic_batch(B, L, seed=31)
+    words = DU.synthetic_random_words(10, 100, seed=31)
+    fake = np.array(words[L - 1][:B], np.int32)
+    res = {}
+    for mode, kw in (("default", {}), ("unfused", {"fuse_passes": False}), ("unshared", {"share_backward": False})):
+        NA._model_counter[0] = 0
+        NA.configure(device=dev, seed=9)
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+        gan = NA.make_gan(G, D, R, S, vis_model=False)
+        for m in (G, D, S):
+            for k in m.store.names:
+                if k.endswith(".sigma"):
+                    m.store.p[k].fill_(0.25)
+        for m in (D, S):
+            m.store.p["dense.w"].mul_(70.0)
+        g2 = torch.Generator().manual_seed(5)
+        nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
+              for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+        opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+        out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], style, B, 128,
+                            net_loss.hinge, 1, 0, None, 10, "", fake_labels=fake, nl=nl, verbose=False, **kw)
+        res[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))})
+        del G, D, R, S, gan
+    sa, ga = res["default"]
+    lines = []
+    for other in ("unfused", "unshared"):
+        sb, gb = res[other]
+        assert np.all(np.abs(sa - sb) <= 1e-5 * np.maximum(1.0, np.abs(sb))), (other, sa, sb)
+        for n in ("D", "R", "S", "G"):
+            scale = gb[n].abs().max().item()
+            err = (ga[n] - gb[n]).abs().max().item()
+            lines.append("%s %s rel %.3e" % (other, n, err / scale))
+            assert err <= (1e-3 if n == "G" else 1e-4) * scale, "%s: %s gradients differ by %.3e of %.3e" % (other, n, err, scale)
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        open("gpurun_out/schedule_equivalence_bs32.txt", "w").write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+
+
 def test_full_state_save_and_resume(dev, tmp_path):
     """save_training_state / load_training_state (the reference cannot resume): three steps in one go against
     two steps, save, rebuild every object from scratch, load, one more step -- same weights, BN statistics and Adam state."""

@@ -33,9 +33,18 @@ FLOP_PER_IMAGE_EXECUTED = 379.1e9 - 2 * 19.891e9   # the shared backward sweep t
 PEAK_FP32_MFMA_TF = 157.3           # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
 
 
-def cpu_baseline(batch=8, L=10):
-    """The oracle's train_step (torch-CPU fp32, all host cores) on a bounded sample: one step at bs 8."""
+def cpu_baseline(batch=8, L=10, warmup=2, timed=5, budget_s=150.0):
+    """The oracle's train_step (torch-CPU fp32, the host cores this process may run on) on a bounded sample, with the
+    protocol of BASELINE.md section 3: bs 8, `warmup` untimed steps, median of `timed` steps.  Runs on rank 0 at N = 1
+    only, after the GPU measurement (outside the timed region).  If the host is so loaded that the protocol would not fit
+    `budget_s`, fewer timed steps are taken and the sample string says so."""
+    import statistics
     from oracle import scrabble_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, cores))
     dt = torch.float32
     g = torch.Generator().manual_seed(1)
     G, D, S, R = O.init_generator(g, dt), O.init_discriminator(g, dt), O.init_discriminator(g, dt), O.init_recognizer(g, dt)
@@ -45,12 +54,61 @@ def cpu_baseline(batch=8, L=10):
     fake = torch.randint(0, 52, (batch, L), generator=g)
     nl = {k: O.init_nonlocal(64, g, dt) for k in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
     opt = {"G": {}, "D": {}, "R": {}, "S": {}}
-    t0 = time.time()
-    O.train_step(images, labels, style, fake, G, D, S, R, nl, opt)
-    dt_s = time.time() - t0
-    return {"value": batch / dt_s, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 train_step of the torch-CPU fp32 oracle at bs %d, 32x160 (stand-in for the TF2 CPU path: TensorFlow is "
-                      "not installable offline)" % batch, "seconds": dt_s}
+    times, t_start = [], time.time()
+    for i in range(warmup + timed):
+        t0 = time.time()
+        O.train_step(images, labels, style, fake, G, D, S, R, nl, opt)
+        times.append(time.time() - t0)
+        done_timed = len(times) - warmup
+        if done_timed >= 1 and (time.time() - t_start) + times[-1] > budget_s:
+            break
+    samples = times[warmup:] if len(times) > warmup else times[-1:]
+    med = statistics.median(samples)
+    return {"value": batch / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU fp32 oracle train_step at bs %d, 32x160 (L = %d): %d warm-up + median of %d timed steps "
+                      "(BASELINE.md section 3); stand-in for the TF2 CPU path, TensorFlow is not installable offline"
+                      % (batch, L, min(warmup, len(times) - len(samples)), len(samples)),
+            "seconds_per_step": med, "all_steps_s": [round(t, 3) for t in times]}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks ourselves (one fresh process per GPU through
+    torch.distributed.run, before this process has touched the GPU), forward rank 0's JSON line, exit with the job's code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
+def dry_run(args):
+    """Launcher rehearsal without a GPU (tests/test_dp_gloo.py): rendezvous, one all-reduce, rank 0 prints a JSON line."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("SG_DIST_BACKEND", "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        ranks, got = dist.get_world_size(), int(t.item())
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks, got, rank = 1, 1, 0
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "rccl_ranks": ranks, "backend": backend, "allreduce_of_ones": got}))
 
 
 def main():
@@ -69,14 +127,22 @@ def main():
                     help="config c4: one (L_r, L_f) pair per step drawn U{4..23}^2 from a stream shared by all ranks (bucket_size 23)")
     ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
     ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + one all-reduce only, no GPU work (launcher rehearsal on CPU)")
     args = ap.parse_args()
+
+    # N > 1 from a bare shell: start the ranks (nothing in this process has touched the GPU yet)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
+    if args.dry_run:
+        return dry_run(args)
 
     from scrabble_gan_amd import data_utils as DU, dist as sdist, net_architecture as NA, net_loss, ops, optimizers
     from scrabble_gan_amd.main import build_models
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE "
+                         "and let bench.py start its own ranks" % (args.gpus, world, args.gpus))
     # SG_DIST_BACKEND=gloo SG_FORCE_DEVICE=0 rehearse the multi-rank path with several ranks on ONE GPU (RCCL needs
     # one device per rank); the driver's runs use the defaults: nccl, one GPU per rank.
     backend = os.environ.get("SG_DIST_BACKEND", "nccl")
@@ -139,7 +205,7 @@ def main():
     # Kernel timing (HIP events around every MFMA conv launch, on the launch stream) runs inside the timed region at
     # N = 1.  At N > 1 the per-GPU batch is small enough for the event records to cost a few percent, so there the
     # timed region runs bare and the roofline figures come from --timing-steps extra steps right after it.
-    timer = None if args.no_kernel_timing else ops.KernelTimer()
+    timer = None if args.no_kernel_timing else ops.KernelTimer(only=("igemm", "wgrad"))      # the MFMA conv kernels (+ their thin variants)
     timing_in_region = timer is not None and world == 1
     ops.PROFILER = timer if timing_in_region else None
     fence()
@@ -170,6 +236,17 @@ def main():
         timed_steps = args.timing_steps
         for o in extra:
             tuple(o)
+    # The memory-bound kernel families (BN, pools, Adam, filter bank, elementwise, attention) are timed in extra steps
+    # AFTER the timed region, so that their ~1 000 event records per step never touch the headline number.
+    hbm_timer = None
+    if timer is not None and args.timing_steps > 0:
+        hbm_timer = ops.KernelTimer()
+        ops.PROFILER = hbm_timer
+        extra = [step(args.steps + args.timing_steps + i) for i in range(args.timing_steps)]
+        fence()
+        ops.PROFILER = None
+        for o in extra:
+            tuple(o)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -193,20 +270,27 @@ def main():
         }
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True
+        line["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1
+        line["backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"
+        line["collectives_per_step"] = getattr(reducer, "calls", 0) / max(1, args.warmup + args.steps) if world > 1 else 0
         if timer is not None:
             try:
                 ks = timer.summary()
                 ig = ks.get("igemm", {"tflops": 0.0, "launches": 0, "ms": 0.0})
                 # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
                 # counters need their own rocprofv3 runs, so the figure is read back, not measured in this process)
-                traffic, traffic_src = None, None
+                def committed_traffic(kernel):
+                    import glob
+                    tag = "%s%s_traffic_bs%d.json" % (kernel, "_bf16" if bf16 else "", B // world)
+                    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + tag)))
+                    if not files:
+                        return None, None
+                    tj = json.load(open(files[-1]))
+                    return tj["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % os.path.basename(files[-1])
                 try:
-                    if bf16:
-                        raise FileNotFoundError
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_igemm_traffic_bs%d.json" % (B // world))))
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_igemm_traffic_bs%d.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % (B // world)
+                    traffic, traffic_src = committed_traffic("igemm")
                 except Exception:  # noqa: BLE001
-                    pass
+                    traffic, traffic_src = None, None
                 line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
                                     "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
                                     "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
@@ -217,6 +301,28 @@ def main():
                                     "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
                 line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
                                        "launches_per_step": v["launches"] / timed_steps} for k, v in ks.items()}
+                if "wgrad" in line["kernels"]:
+                    wg = ks["wgrad"]
+                    try:
+                        wt, wsrc = committed_traffic("wgrad")
+                    except Exception:  # noqa: BLE001
+                        wt, wsrc = None, None
+                    line["kernels"]["wgrad"].update({"frac_of_mfma_peak": round(wg["tflops"] / peak_tf, 4), "traffic": wt, "traffic_source": wsrc})
+                if hbm_timer is not None:
+                    # memory-bound families: algorithmic bytes (every operand once + every result once) / HIP-event time,
+                    # against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy reaches)
+                    hs, nst = hbm_timer.summary(), args.timing_steps
+                    line["hbm_kernels"] = {}
+                    for k, v in sorted(hs.items(), key=lambda kv: -kv[1]["ms"]):
+                        roof = hbm_timer.roof.get(k, "hbm")
+                        if roof == "mfma" or v["ms"] <= 0:
+                            continue
+                        gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                        ent = {"bound": roof, "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] / nst,
+                               "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
+                        if v["flops"]:
+                            ent["tflops"] = round(v["tflops"], 2)
+                        line["hbm_kernels"][k] = ent
             except Exception as e:  # noqa: BLE001  (the headline numbers above must still be printed)
                 line["roofline_error"] = repr(e)
         if timer is not None and args.shape_table:

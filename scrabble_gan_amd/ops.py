@@ -20,10 +20,15 @@ class KernelTimer:
     """HIP-event timing of kernel families on the stream the kernels are launched on (bench.py's
     roofline leg).  `flops` is the algorithmic 2*M*N*K of the launch."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}
         self.shapes = {}
         self.nbytes = {}        # algorithmic bytes (operands read once + result written once) per family
+        self.only = only        # None = every family; else the set of family-name prefixes to time
+        self.roof = {}          # family -> "mfma" | "hbm" | "valu"
+
+    def wants(self, family):
+        return self.only is None or any(family.startswith(p) for p in self.only)
 
     class _Region:
         def __init__(self, timer, family, flops, tag=None, nbytes=0.0):
@@ -81,7 +86,20 @@ PROFILER: Optional[KernelTimer] = None
 def _timed(family: str, flops: float, thin: bool, tag=None, tensors=()):
     if PROFILER is None:
         return _NULL
-    return PROFILER.region(family + ("_thin" if thin else ""), flops, tag, 4.0 * sum(t.numel() for t in tensors if t is not None))
+    fam = family + ("_thin" if thin else "")
+    if not PROFILER.wants(fam):
+        return _NULL
+    PROFILER.roof[fam] = "hbm" if thin else "mfma"
+    return PROFILER.region(fam, flops, tag, float(sum(t.numel() * t.element_size() for t in tensors if t is not None)))
+
+
+def _hbm(family: str, *tensors, flops: float = 0.0, roof: str = "hbm"):
+    """Timed region of a memory-bound kernel family: algorithmic bytes = every operand read once + every result
+    written once (bench.py reports GB/s against the 8 TB/s HBM peak)."""
+    if PROFILER is None or not PROFILER.wants(family):
+        return _NULL
+    PROFILER.roof[family] = roof
+    return PROFILER.region(family, flops, None, float(sum(t.numel() * t.element_size() for t in tensors if t is not None)))
 
 
 _DEV_INDEX = None
@@ -281,7 +299,8 @@ def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
 def bias_grad(dy, db):
     _chk(dy, db)
     N = dy.shape[-1]
-    call("sg_bias_grad", _p(dy), _p(db), dy.numel() // N, N, _stream())
+    with _hbm("bias_grad", dy):
+        call("sg_bias_grad", _p(dy), _p(db), dy.numel() // N, N, _stream())
 
 
 # ---------------------------------------------------------------- pooling / elementwise
@@ -289,7 +308,8 @@ def avgpool2_add_fwd(a, b=None):
     _chk(a, b)
     B, H, W, C = a.shape
     out = empty(B, H // 2, W // 2, C, like=a)
-    call("sg_avgpool2_add_fwd", _p(a), _p(b), _p(out), B, H, W, C, _stream())
+    with _hbm("pool", a, b, out):
+        call("sg_avgpool2_add_fwd", _p(a), _p(b), _p(out), B, H, W, C, _stream())
     return out
 
 
@@ -297,7 +317,8 @@ def avgpool2_bwd(dout):
     _chk(dout)
     B, Ho, Wo, C = dout.shape
     dx = empty(B, 2 * Ho, 2 * Wo, C, like=dout)
-    call("sg_avgpool2_bwd", _p(dout), _p(dx), B, 2 * Ho, 2 * Wo, C, _stream())
+    with _hbm("pool", dout, dx):
+        call("sg_avgpool2_bwd", _p(dout), _p(dx), B, 2 * Ho, 2 * Wo, C, _stream())
     return dx
 
 
@@ -306,7 +327,8 @@ def add(a, b, out=None):
     assert a.shape == b.shape
     if out is None:
         out = torch.empty_like(a)
-    call("sg_add", _p(a), _p(b), _p(out), a.numel(), _stream())
+    with _hbm("elementwise", a, b, out):
+        call("sg_add", _p(a), _p(b), _p(out), a.numel(), _stream())
     return out
 
 
@@ -314,14 +336,16 @@ def relu_mask(dy, ref, out=None):
     _chk(dy, ref, out)
     if out is None:
         out = torch.empty_like(dy)
-    call("sg_relu_mask", _p(dy), _p(ref), _p(out), dy.numel(), _stream())
+    with _hbm("elementwise", dy, ref, out):
+        call("sg_relu_mask", _p(dy), _p(ref), _p(out), dy.numel(), _stream())
     return out
 
 
 def tanh_bwd(y, dy):
     _chk(y, dy)
     dx = torch.empty_like(dy)
-    call("sg_tanh_bwd", _p(y), _p(dy), _p(dx), dy.numel(), _stream())
+    with _hbm("elementwise", y, dy, dx):
+        call("sg_tanh_bwd", _p(y), _p(dy), _p(dx), dy.numel(), _stream())
     return dx
 
 
@@ -330,7 +354,8 @@ def maxpool_fwd(x, ph, pw):
     B, H, W, C = x.shape
     y = empty(B, H // ph, W // pw, C, like=x)
     idx = empty(B, H // ph, W // pw, C, like=x, dtype=torch.uint8)
-    call("sg_maxpool_fwd", _p(x), _p(y), idx.data_ptr(), B, H, W, C, ph, pw, _stream())
+    with _hbm("pool", x, y, idx):
+        call("sg_maxpool_fwd", _p(x), _p(y), idx.data_ptr(), B, H, W, C, ph, pw, _stream())
     return y, idx
 
 
@@ -339,7 +364,8 @@ def maxpool_bwd(dy, idx, ph, pw, out=None, accum=False):
     B, Ho, Wo, C = dy.shape
     if out is None:
         out = empty(B, Ho * ph, Wo * pw, C, like=dy)
-    call("sg_maxpool_bwd", _p(dy), idx.data_ptr(), _p(out), B, Ho * ph, Wo * pw, C, ph, pw, int(accum), _stream())
+    with _hbm("pool", dy, idx, out):
+        call("sg_maxpool_bwd", _p(dy), idx.data_ptr(), _p(out), B, Ho * ph, Wo * pw, C, ph, pw, int(accum), _stream())
     return out
 
 
@@ -347,7 +373,8 @@ def gap_fwd(x, relu=True):
     _chk(x)
     B, H, W, C = x.shape
     out = empty(B, C, like=x)
-    call("sg_gap_fwd", _p(x), _p(out), B, H * W, C, int(relu), _stream())
+    with _hbm("pool", x, out):
+        call("sg_gap_fwd", _p(x), _p(out), B, H * W, C, int(relu), _stream())
     return out
 
 
@@ -355,7 +382,8 @@ def gap_bwd(dout, x, relu=True):
     _chk(dout, x)
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    call("sg_gap_bwd", _p(dout), _p(x), _p(dx), B, H * W, C, int(relu), _stream())
+    with _hbm("pool", dout, x, dx):
+        call("sg_gap_bwd", _p(dout), _p(x), _p(dx), B, H * W, C, int(relu), _stream())
     return dx
 
 
@@ -363,27 +391,31 @@ def scale_add(o, x, sigma, out=None):
     _chk(o, x, sigma, out)
     if out is None:
         out = torch.empty_like(x)
-    call("sg_scale_add", _p(o), _p(x), _p(sigma), _p(out), x.numel(), _stream())
+    with _hbm("elementwise", o, x, out):
+        call("sg_scale_add", _p(o), _p(x), _p(sigma), _p(out), x.numel(), _stream())
     return out
 
 
 def scale(a, s):
     _chk(a, s)
     out = torch.empty_like(a)
-    call("sg_scale", _p(a), _p(s), _p(out), a.numel(), _stream())
+    with _hbm("elementwise", a, out):
+        call("sg_scale", _p(a), _p(s), _p(out), a.numel(), _stream())
     return out
 
 
 def dot_accum(a, b, out):
     _chk(a, b, out)
-    call("sg_dot_accum", _p(a), _p(b), _p(out), a.numel(), _stream())
+    with _hbm("elementwise", a, b):
+        call("sg_dot_accum", _p(a), _p(b), _p(out), a.numel(), _stream())
 
 
 def rowscale(x, s):
     _chk(x, s)
     out = torch.empty_like(x)
     rows = s.numel()
-    call("sg_rowscale", _p(x), _p(s), _p(out), rows, x.numel() // rows, _stream())
+    with _hbm("elementwise", x, out):
+        call("sg_rowscale", _p(x), _p(s), _p(out), rows, x.numel() // rows, _stream())
     return out
 
 
@@ -430,7 +462,8 @@ def bn_stats_sums(x):
     M = x.numel() // C
     ws = empty(lib().sg_bn_stats_workspace_floats(M, C), like=x)
     sums = empty(2 * C, like=x, dtype=torch.float64)
-    call("sg_bn_stats_sums", _p(x), M, C, _p(ws), sums.data_ptr(), _stream())
+    with _hbm("bn_stats", x):
+        call("sg_bn_stats_sums", _p(x), M, C, _p(ws), sums.data_ptr(), _stream())
     return sums
 
 
@@ -445,7 +478,8 @@ def bn_apply(x, mean, var, gamma, beta, per_sample: bool, relu: bool, eps=BN_EPS
     _chk(x, mean, var, gamma, beta)
     B, H, W, C = x.shape
     y = torch.empty_like(x)
-    call("sg_bn_apply", _p(x), _p(mean), _p(var), _p(gamma), _p(beta), C if per_sample else 0, _p(y), B, H * W, C, eps, int(relu), _stream())
+    with _hbm("bn_apply", x, y):
+        call("sg_bn_apply", _p(x), _p(mean), _p(var), _p(gamma), _p(beta), C if per_sample else 0, _p(y), B, H * W, C, eps, int(relu), _stream())
     return y
 
 
@@ -456,8 +490,9 @@ def bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample: bool, relu: bool, eps=
     dgamma = torch.zeros(B, C, device=x.device, dtype=torch.float32)
     dbeta = torch.zeros(B, C, device=x.device, dtype=torch.float32)
     chan = empty(4 * C, like=x, dtype=torch.float64)
-    call("sg_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0, _p(dgamma), _p(dbeta),
-         chan.data_ptr(), _p(dgamma_c), _p(dbeta_c), B, H * W, C, eps, int(relu), _stream())
+    with _hbm("bn_bwd_reduce", dy, y, x):
+        call("sg_bn_bwd_reduce", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0, _p(dgamma), _p(dbeta),
+             chan.data_ptr(), _p(dgamma_c), _p(dbeta_c), B, H * W, C, eps, int(relu), _stream())
     return dgamma, dbeta, chan
 
 
@@ -465,8 +500,9 @@ def bn_bwd_apply(dy, y, x, mean, var, gamma, per_sample: bool, chan, count, relu
     _chk(dy, y, x, mean, var, gamma)
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    call("sg_bn_bwd_apply", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0,
-         None if chan is None else chan.data_ptr(), float(count), _p(dx), B, H * W, C, eps, int(relu), int(use_stats), _stream())
+    with _hbm("bn_bwd_apply", dy, y, x, dx):
+        call("sg_bn_bwd_apply", _p(dy), _p(y), _p(x), _p(mean), _p(var), _p(gamma), C if per_sample else 0,
+             None if chan is None else chan.data_ptr(), float(count), _p(dx), B, H * W, C, eps, int(relu), int(use_stats), _stream())
     return dx
 
 
@@ -482,14 +518,16 @@ def filterbank_fwd(z, y, table):
     assert y.dtype == torch.int32 and y.is_contiguous() and z.shape[1] == 128
     assert table.shape[1] == 32 and table.shape[2] == 8192
     seed = empty(B, 4, 4 * L, 512, like=z)
-    call("sg_filterbank_fwd", _p(z), y.data_ptr(), _p(table), _p(seed), B, L, table.shape[0], _stream())
+    with _hbm("filterbank_fwd", seed, table):
+        call("sg_filterbank_fwd", _p(z), y.data_ptr(), _p(table), _p(seed), B, L, table.shape[0], _stream())
     return seed
 
 
 def filterbank_bwd(z, y, table, dseed, dtable, dz):
     _chk(z, table, dseed, dtable, dz)
     B, L = y.shape
-    call("sg_filterbank_bwd", _p(z), y.data_ptr(), _p(table), _p(dseed), _p(dtable), _p(dz), B, L, table.shape[0], _stream())
+    with _hbm("filterbank_bwd", dseed, table, dtable):
+        call("sg_filterbank_bwd", _p(z), y.data_ptr(), _p(table), _p(dseed), _p(dtable), _p(dz), B, L, table.shape[0], _stream())
 
 
 # ---------------------------------------------------------------- attention
@@ -499,7 +537,8 @@ def attention_fwd(theta, phi, g):
     Nk, dv = g.shape[1], g.shape[2]
     out = empty(B, Nq, dv, like=theta)
     lse = empty(B, Nq, like=theta)
-    call("sg_attention_fwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), B, Nq, Nk, dk, dv, _stream())
+    with _hbm("attention_fwd", theta, phi, g, out, flops=2.0 * B * Nq * Nk * (dk + dv), roof="valu"):
+        call("sg_attention_fwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), B, Nq, Nk, dk, dv, _stream())
     return out, lse
 
 
@@ -509,8 +548,9 @@ def attention_bwd(theta, phi, g, out, lse, dout):
     Nk, dv = g.shape[1], g.shape[2]
     dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
     delta = empty(B, Nq, like=theta)
-    call("sg_attention_bwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), _p(dout), _p(dtheta), _p(dphi), _p(dg), _p(delta),
-         B, Nq, Nk, dk, dv, _stream())
+    with _hbm("attention_bwd", theta, phi, g, out, dout, dtheta, dphi, dg, flops=2.0 * B * Nq * Nk * (3 * dk + 2 * dv + dv), roof="valu"):
+        call("sg_attention_bwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), _p(dout), _p(dtheta), _p(dphi), _p(dg), _p(delta),
+             B, Nq, Nk, dk, dv, _stream())
     return dtheta, dphi, dg
 
 
@@ -547,13 +587,15 @@ def loss_grads(d_r, d_f, s_my, s_f, s_r, r_f, mode: int, balance: bool, alpha: f
 # ---------------------------------------------------------------- optimizers / spectral norm
 def adam_update(p, g, m, v, lr_t, beta_1, beta_2, eps=1e-7):
     _chk(p, g, m, v)
-    call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
+    with _hbm("adam", p, p, g, m, m, v, v):
+        call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
     weights_changed()
 
 
 def rmsprop_update(p, g, ms, lr, rho=0.9, eps=1e-7):
     _chk(p, g, ms)
-    call("sg_rmsprop_update", _p(p), _p(g), _p(ms), p.numel(), float(lr), float(rho), float(eps), _stream())
+    with _hbm("adam", p, p, g, ms, ms):
+        call("sg_rmsprop_update", _p(p), _p(g), _p(ms), p.numel(), float(lr), float(rho), float(eps), _stream())
     weights_changed()
 
 

@@ -412,12 +412,14 @@ def adam_update(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: dict
 
 
 def rmsprop_update(params, grads, state, lr: float, rho: float = 0.9, eps: float = 1e-7) -> None:
+    """tf.keras.optimizers.RMSprop(lr) of main.py:29-30 (rho 0.9, momentum 0, epsilon 1e-7, not centered), TF 2.1 dense
+    path: rms = rho rms + (1-rho) g^2 ; var -= lr g / (sqrt(rms) + epsilon)  -- epsilon is added OUTSIDE the root."""
     for k, g in grads.items():
         if g is None:
             continue
         ms = state.setdefault("ms." + k, torch.zeros_like(params[k]))
         ms.mul_(rho).addcmul_(g, g, value=1.0 - rho)
-        params[k] = params[k] - lr * g / torch.sqrt(ms + eps)
+        params[k] = params[k] - lr * g / (torch.sqrt(ms) + eps)
 
 
 # --------------------------------------------------------------------------------------------

@@ -48,9 +48,17 @@ __global__ __launch_bounds__(64) void k_softmax_ctc(const float* logits, const i
     }
   }
   int lab = blank;
+  bool bad = false;
   if (lane < S && (lane & 1)) {
     lab = labels[(size_t)b * label_stride + (lane >> 1)];
-    lab = lab < 0 ? 0 : (lab >= C ? C - 1 : lab);
+    bad = lab < 0 || lab >= blank;          // K.ctc_batch_cost rejects labels outside [0, C-2]; never train on a clamped target
+    lab = bad ? 0 : lab;
+  }
+  if (__ballot(bad) != 0ull) {             // wave-uniform: poison this sample loudly (cost +inf, NaN gradient) instead of clamping
+    if (lane == 0) loss[b] = INFINITY;
+    if (dlogits)
+      for (int e = lane; e < T * C; e += 64) dlogits[(size_t)b * T * C + e] = __builtin_nanf("");
+    return;
   }
   labs[lane] = lab;
   __syncthreads();
@@ -127,8 +135,11 @@ extern "C" int sg_softmax_ctc(const float* logits, const int* labels, int label_
   const int S = 2 * label_length + 1;
   const size_t lds = (size_t)(2 * T * C + 2 * T * S) * sizeof(float);
   if (lds > 150 * 1024) return SG_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_softmax_ctc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_softmax_ctc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return SG_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(k_softmax_ctc, dim3(B), dim3(64), lds, (hipStream_t)stream, logits, labels, label_stride, loss, dlogits, T, C,
                      input_length, label_length);
   return sg_launch_status();

@@ -33,13 +33,14 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
   }
 }
 
-// Keras RMSprop (momentum 0, not centered): ms = rho ms + (1-rho) g^2 ; p -= lr g / sqrt(ms + eps)
+// Keras RMSprop, TF 2.1 non-fused dense path (momentum 0, not centered; rmsprop.py _resource_apply_dense):
+//   ms = rho ms + (1-rho) g^2 ; p -= lr g / (sqrt(ms) + eps)      -- eps OUTSIDE the root
 __global__ __launch_bounds__(256) void k_rmsprop(float* p, const float* g, float* ms, long n, float lr, float rho, float eps) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const float gv = g[e];
     const float s = rho * ms[e] + (1.f - rho) * gv * gv;
     ms[e] = s;
-    p[e] -= lr * gv / sqrtf(s + eps);
+    p[e] -= lr * gv / (sqrtf(s) + eps);
   }
 }
 

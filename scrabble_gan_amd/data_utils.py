@@ -125,9 +125,14 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     # ---- host RNG + shapes (:385-395); tf.random.normal `noise` is unused by the reference graph ----
     if fake_labels is None:
         random_bucket_idx, fake_labels = draw_fake_labels(random_words, bucket_size, batch_size)
+        if red.world_size > 1:
+            # every rank must shard the SAME global batch (same L_f, same words): take rank 0's draw, whatever the state of
+            # this rank's `random` stream (main.py seeds all ranks alike, other callers may not) -- ADVICE r1
+            fake_labels = red.broadcast_object(fake_labels)
     images = _as_nhwc1(images, dev)
-    labels_t = _as_labels(labels, dev)
-    fake_t = _as_labels(fake_labels, dev)
+    n_chars = G.store.shapes["filter_bank"][0]                      # vocabulary size = CTC classes - 1 (blank is the last class)
+    labels_t = _as_labels(labels, dev, n_chars)
+    fake_t = _as_labels(fake_labels, dev, n_chars)
     if isinstance(my_imgs, (list, tuple)):
         my_imgs = np.stack([np.asarray(m) for m in my_imgs], axis=0) if not torch.is_tensor(my_imgs[0]) else torch.stack(list(my_imgs), 0)
     style = _as_nhwc1(my_imgs, dev)
@@ -377,9 +382,13 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
     at start, loaded first -- training continues with the epoch after the saved one."""
     generator_save_dir = os.path.join(checkpoint_prefix, 'generator/')
     recognizer_save_dir = os.path.join(checkpoint_prefix, 'recognizer/')
-    os.makedirs(generator_save_dir, exist_ok=True)
-    os.makedirs(recognizer_save_dir, exist_ok=True)
-    os.makedirs(gen_path, exist_ok=True)
+    # data parallel: every rank runs the loop (same seeded host streams -> same batches, each rank takes its slice inside
+    # train_step); only rank 0 writes summaries and checkpoints
+    is_main = getattr(generator.reducer, "rank", 0) == 0
+    if is_main:
+        os.makedirs(generator_save_dir, exist_ok=True)
+        os.makedirs(recognizer_save_dir, exist_ok=True)
+        os.makedirs(gen_path, exist_ok=True)
     batch_per_epoch = int(buffer_size / batch_size) + 1
     if max_batches_per_epoch is not None:
         batch_per_epoch = min(batch_per_epoch, max_batches_per_epoch)
@@ -395,8 +404,8 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
         first_epoch = saved_epoch + 1
         print('resumed from %s: continuing with epoch %d' % (state_path, first_epoch + 1))
     mode = "a" if first_epoch > 0 else "w"                   # a resumed run appends to the summaries of the first one
-    with open(os.path.join(gen_path, "batch_summary.txt"), mode) as batch_summary, \
-            open(os.path.join(gen_path, "epoch_summary.txt"), mode) as epoch_summary:
+    with open(os.path.join(gen_path, "batch_summary.txt") if is_main else os.devnull, mode) as batch_summary, \
+            open(os.path.join(gen_path, "epoch_summary.txt") if is_main else os.devnull, mode) as epoch_summary:
         if first_epoch == 0:
             epoch_summary.write(SUMMARY_HEADER)
             batch_summary.write(SUMMARY_HEADER)
@@ -423,6 +432,8 @@ def train(dataset, generator, discriminator, recognizer, style_promoter, composi
                 flush(pending)
             epoch_summary.write(";".join(str(totals[i] / batch_per_epoch) for i in order) + "\n")
             print('Time for epoch {} is {} sec'.format(epoch_idx + 1, time.time() - start))
+            if not is_main:
+                continue
             generator.save_weights(os.path.join(generator_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
             recognizer.save_weights(os.path.join(recognizer_save_dir, str(epoch_idx + 1), 'cktp-' + str(epoch_idx + 1)))
             if state_path is not None:

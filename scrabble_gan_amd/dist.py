@@ -21,8 +21,11 @@ class DistReducer(Reducer):
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+    calls = 0          # collectives issued (bench.py reports them per step)
+
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
+            self.calls += 1
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -31,11 +34,19 @@ class DistReducer(Reducer):
         current stream), so D/R/S gradient exchange overlaps the generator's backward sweep."""
         if self.world_size == 1:
             return None
+        self.calls += 1
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self, handle) -> None:
         if handle is not None:
             handle.wait()        # makes the current stream wait for the collective; no host block on nccl
+
+    def broadcast_object(self, obj, src: int = 0):
+        """Rank `src`'s Python object on every rank (host-side; used for the per-step host draws when a caller did not
+        seed the ranks' `random` streams identically)."""
+        box = [obj if self.rank == src else None]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
 
     def shard(self, t: torch.Tensor) -> torch.Tensor:
         """This rank's contiguous slice [r*B/P, (r+1)*B/P) of a per-step batch tensor."""

@@ -88,14 +88,25 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="cap batches per epoch")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the host RNG streams (random, numpy) and of the weight initialisers")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="no float-atomic reduction splits in the conv kernels: bitwise reproducible runs, a few percent slower")
     args = ap.parse_args(argv)
+
+    # Data parallel (one process per GPU under torch.distributed.run): join the job BEFORE any GPU work, give every rank the
+    # same host RNG streams (bucket choice, fake words, style images: every rank must see the same global batch and take its
+    # slice) and the same initial weights.  A single process gets the identity reducer.
+    from . import dist as sdist
+    reducer = sdist.init_from_env(os.environ.get("SG_DIST_BACKEND", "nccl"))
+    random.seed(args.seed)
+    np.random.seed(args.seed)
 
     gin.parse_config_file(args.gin)
     epochs, batch_size, latent_dim, embed_y, num_gen, kernel_reg, g_bw_attention, d_bw_attention, my_rec, my_disc = get_shared_specs()
     in_dim, buf_size, n_classes, seq_len, bucket_size, ckpt_path, gen_path, m_path, raw_dir, read_dir, char_vec = setup_io()
     epochs = args.epochs or epochs
     batch_size = args.batch_size or batch_size
-    configure(conv_dtype=args.conv_dtype)
+    configure(conv_dtype=args.conv_dtype, seed=args.seed, reducer=reducer, deterministic=args.deterministic)
 
     if args.synthetic:
         random_words = synthetic_random_words(bucket_size, 1000, n_classes)
@@ -110,7 +121,8 @@ def main(argv=None):
         train_imgs, _ = load_style_input(in_dim, batch_size, bucket_size)
 
     generator, discriminator, recognizer, style_promoter, gan = build_models(
-        in_dim, latent_dim, embed_y, kernel_reg, g_bw_attention, d_bw_attention, n_classes, seq_len, my_rec, my_disc, vis_model=True)
+        in_dim, latent_dim, embed_y, kernel_reg, g_bw_attention, d_bw_attention, n_classes, seq_len, my_rec, my_disc,
+        vis_model=getattr(reducer, "rank", 0) == 0)
     (generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, loss_fn, disc_iters,
      apply_gradient_balance) = setup_optimizer()
 

@@ -50,11 +50,19 @@ def get_in_out_channels_disc(colors=1, resolution=32):
 _DEFAULTS = {"device": None, "seed": 0, "nl_mode": "reference", "reducer": LOCAL}
 
 
-def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=None):
+def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=None, deterministic=None):
     """Process-wide construction defaults (device, init seed, NonLocalBlock mode, DP reducer) and the matrix-core
-    operand type of the convolutions ('f32' = parity mode, 'bf16' = BASELINE config c3)."""
+    operand type of the convolutions ('f32' = parity mode, 'bf16' = BASELINE config c3).
+
+    deterministic=True: the forward / data-grad conv kernels never split a reduction across workgroups, so no activation
+    and no image gradient is summed by float atomics: they are bitwise reproducible from launch to launch and independent
+    of the per-rank batch size (a few percent slower: the tail tiles of a launch no longer balance over the CUs).  The
+    weight-gradient, bias-gradient and attention-dK/dV kernels still add partial sums with float atomics, so weights agree
+    between runs to fp32 rounding, not bitwise.  Default runs are NOT bitwise reproducible (README)."""
     if conv_dtype is not None:
         ops.set_conv_dtype(conv_dtype)
+    if deterministic is not None:
+        ops.set_deterministic(bool(deterministic))
     if device is not None:
         _DEFAULTS["device"] = torch.device(device)
     if seed is not None:
@@ -273,10 +281,18 @@ def _as_nhwc1(x, device):
     return x.to(device=device, dtype=torch.float32).contiguous()
 
 
-def _as_labels(y, device):
+def _as_labels(y, device, n_classes=None):
+    """int32 labels on the device.  Host arrays (the train loop's case) are range-checked here when `n_classes` is given:
+    TF's ctc_batch_cost / embedding_lookup reject indices outside [0, n_classes), and a bad char_vector or label file must
+    not train on silently clamped targets.  (Device-resident labels: the CTC kernel poisons the sample's cost with +inf.)"""
     if not torch.is_tensor(y):
         import numpy as np
-        y = torch.from_numpy(np.ascontiguousarray(y))
+        y = np.ascontiguousarray(y)
+        if n_classes is not None and y.size and (y.min() < 0 or y.max() >= n_classes):
+            raise ValueError("label outside [0, %d): min %d, max %d" % (n_classes, y.min(), y.max()))
+        y = torch.from_numpy(y)
+    elif n_classes is not None and not y.is_cuda and y.numel() and (int(y.min()) < 0 or int(y.max()) >= n_classes):
+        raise ValueError("label outside [0, %d)" % n_classes)
     return y.to(device=device, dtype=torch.int32).contiguous()
 
 

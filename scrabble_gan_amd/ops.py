@@ -154,6 +154,12 @@ def set_conv_dtype(dtype: str) -> None:
     _PACK_CACHE.clear()
 
 
+def set_deterministic(on: bool) -> None:
+    """on: force every conv launch to one workgroup per output tile (no split reductions / float atomics in the forward
+    and data-grad kernels).  off: the default CU-quantum tail split."""
+    lib().sg_debug_set_splitk(1 if on else -1)
+
+
 def weights_changed() -> None:
     """Called by the optimizers (and anything else that rewrites parameters through raw pointers): the packed bf16
     filter copies are stale."""
@@ -559,6 +565,9 @@ def softmax_ctc(logits, labels, input_length, label_length, need_grad=True):
     _chk(logits)
     B, T, C = logits.shape
     assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.shape[0] == B
+    if not (0 < int(label_length) <= labels.shape[1]) or not (0 < int(input_length) <= T):
+        raise ValueError("CTC lengths out of range: input_length %d (T = %d), label_length %d (labels %s)"
+                         % (input_length, T, label_length, tuple(labels.shape)))
     loss = empty(B, like=logits)
     dlogits = torch.empty_like(logits) if need_grad else None
     call("sg_softmax_ctc", _p(logits), labels.data_ptr(), labels.shape[1], _p(loss), _p(dlogits), B, T, C, int(input_length),

@@ -75,3 +75,27 @@ def test_dp_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): bench.py launches two fresh rank processes through
+    torch.distributed.run, they rendezvous on 127.0.0.1 and rank 0 prints ONE JSON line.  --dry-run keeps
+    the rehearsal GPU-free: the rendezvous and one SUM all-reduce, over gloo here (RCCL on the GPU node)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SG_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["rccl_ranks"] == 2 and out["allreduce_of_ones"] == 2 and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    # a rank failure must surface as a non-zero exit code of the launcher
+    env["SG_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0

@@ -366,6 +366,12 @@ def test_adam_rmsprop_spectral(dev, gen):
         O.rmsprop_update(P2, {"w": g}, st2, 2e-4)
         ops.rmsprop_update(pg2, gg, ms, 2e-4)
     close(pg2, P2["w"], tol=1e-6, name="rmsprop")
+    # gradients far below sqrt(eps): epsilon sits OUTSIDE the root (TF 2.1 dense path), hand-computed first step
+    gs = torch.tensor([1.0, -1e-3, 1e-6, 1e-9] * 2, dtype=torch.float64)
+    pz, msz = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+    ops.rmsprop_update(pz, g32(gs, dev), msz, 2e-4)
+    want = -2e-4 * gs / (math.sqrt(0.1) * gs.abs() + 1e-7)
+    assert ((pz.double().cpu() - want).abs() <= 2e-6 * want.abs()).all(), (pz, want)
     w, u = rnd(gen, 3, 3, 16, 40), rnd(gen, 1, 40)
     close(ops.spectral_norm(g32(w, dev), g32(u.reshape(-1), dev)), O.spectral_norm(w, u), tol=2e-5, name="spectral_norm")
     close(ops.spectral_norm(g32(w, dev), g32(u.reshape(-1), dev), 3), O.spectral_norm(w, u, 3), tol=2e-5, name="spectral_norm3")

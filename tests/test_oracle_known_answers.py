@@ -238,3 +238,17 @@ def test_generator_inference_mode_uses_moving_statistics():
     assert (train - cold).abs().max().item() > 1e-3
     assert (train - warm).abs().max().item() < 1e-12
     assert set(stats) == {"B1.cbn1", "B1.cbn2", "B2.cbn1", "B2.cbn2", "B3.cbn1", "B3.cbn2", "bn"}
+
+
+def test_rmsprop_first_step_closed_form_with_small_gradients():
+    """Keras RMSprop of TF 2.1 (momentum 0, not centered): rms = 0.1 g^2 after the first step, so
+    delta = -lr g / (sqrt(0.1) |g| + 1e-7) -- epsilon OUTSIDE the root.  Hand values with gradients down to
+    1e-9, where the two epsilon placements differ by orders of magnitude: for g = 1e-9 the step is
+    -lr * 1e-9 / (3.162e-10 + 1e-7) = -lr * 9.968e-3, while eps inside the root would give -lr * 3.16e-6."""
+    g_ = torch.tensor([1.0, -1e-3, 1e-6, 1e-9], dtype=torch.float64)
+    P, st = {"w": torch.zeros(4, dtype=torch.float64)}, {}
+    O.rmsprop_update(P, {"w": g_}, st, lr=2e-4)
+    want = -2e-4 * g_ / (math.sqrt(0.1) * g_.abs() + 1e-7)
+    assert torch.allclose(P["w"], want, rtol=1e-12, atol=0)
+    assert abs(P["w"][3].item() / (-2e-4) - 9.96847e-3) < 1e-7
+    assert abs(P["w"][0].item() / (-2e-4) - 1 / (math.sqrt(0.1) + 1e-7)) < 1e-9

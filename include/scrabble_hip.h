@@ -63,6 +63,27 @@ int sg_conv2d_fwd_bf16(const float* x, const void* wp_fwd, const float* bias, co
 int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, const float* mask, float* dx,
                             int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
+ *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale
+ *      (nullable, [n / rowlen], rowlen % 8 == 0) multiplies row r by rowscale[r] first (the per-sample factors of the shared
+ *      backward sweep, data_utils.py:449-468 of the reference run as one sweep).
+ *      sg_conv2d_fwd_bf16v2 / sg_conv2d_bwd_data_bf16v2: contracts of sg_conv2d_fwd / sg_conv2d_bwd_data
+ *      (resnet_ops.py:65,98,103,109) with the activation operand given as a bf16 NHWC tensor (x16 / dy16), the filter as the
+ *      packed copy of sg_pack_filter_bf16, an fp32 result and, when y16 / dx16 is non-null, a bf16 copy of the result
+ *      for the next launch.  SG_ERR_UNSUPPORTED unless reduction channels % 64 == 0 and output channels % 256 == 0:
+ *      the caller then uses sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor. ----------------------- */
+int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream);
+int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
+                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, float* dx, void* dx16,
+                              int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+/* dw [kh,kw,Cin,Cout] (fp32) += weight gradient of the SAME stride-1 convolution from bf16 operands x16 [B,H,W,Cin] and
+ * dy16 [B,H,W,Cout] (tape of d_loss / s_loss / g_final, data_utils.py:449-468; per-sample factors already folded into dy16 by
+ * sg_cvt_bf16).  flags: SG_RELU_IN on x16.  No bias gradient (sg_bias_grad).  SG_ERR_UNSUPPORTED unless Cin % 256 == 0 and
+ * Cout % 256 == 0: the caller then uses sg_conv2d_bwd_weight. */
+int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
+                                int kh, int kw, int pad_same, int flags, void* stream);
+
 /* bf16 variants of the transposed convolution (w [kh,kw,Cout,Cin]): forward wp = pack(w, kh*kw, K = Cin, N = Cout,
  * transpose = 0); data-grad wp = pack(w, kh*kw, K = Cout, N = Cin, transpose = 1).  SG_ERR_UNSUPPORTED for a stride /
  * kernel combination with a tap-less parity class (1x1, stride 2) and for K % 8 != 0 or N <= 32: use the fp32 entry. */

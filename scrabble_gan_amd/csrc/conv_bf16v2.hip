@@ -1,0 +1,715 @@
+// bf16 implicit-GEMM convolution, second generation (config c3 of BASELINE.json): bf16 ACTIVATIONS IN HBM, operand
+// tiles moved global -> LDS by the DMA path (global_load_lds_dwordx4), 256x256 tiles, 8 waves with 128x64 wave tiles.
+//
+// Why (round-1 measurement): the first bf16 kernel reads fp32 activations, rounds them in
+// registers and writes the tiles with ds_write -- per k-tile the three resident workgroups of a CU push 48 KB through the
+// VGPR->LDS store path (~80 B/clk peak) and read 96 KB of fragments with 64x64 wave tiles: the LDS pipe, not the matrix
+// core, set the rate (22 % of the dense bf16 peak).  Here
+//   * the activation operand is a bf16 NHWC tensor (written by the producing kernel's epilogue or by sg_cvt_bf16), so an
+//     operand row of one k-tile is ONE 128-byte line = 64 channels of one pixel at one tap;
+//   * both tiles go global -> LDS without touching a VGPR: 8 x global_load_lds_dwordx4 per thread and k-tile.  The LDS
+//     image of a wave instruction is lane-linear (8 rows x 128 B), so the bank swizzle sits on the SOURCE side: the lane
+//     that owns 16-byte slot p of row r fetches k-chunk p ^ ((r >> 1) & 7); a fragment read of chunk c goes to slot
+//     c ^ ((r >> 1) & 7) -- conflict-free for ds_read_b128's 16-lane groups;
+//   * a row that must contribute zeros (padding tap, pixel past the end of the batch) fetches from a 256-byte zero page
+//     in device memory instead of its pixel -- no select after the load, no dependence on out-of-range semantics;
+//   * ReLU on the operand is a packed signed 16-bit max on the FRAGMENT registers (bf16 is negative iff its int16 is);
+//   * 128x64 wave tiles: 6 ds_read_b128 per 8 MFMAs (0.75 KB per MFMA instead of 1 KB), fragment reads one k-step ahead;
+//   * two 64 KB stages (A 256x64 + B 256x64, bf16).  One workgroup barrier per k-tile, placed after the fragment reads of
+//     the tile's LAST k-step have returned: behind it the other stage's data has landed (each wave waited for its own DMAs)
+//     and this stage is free, so the DMAs of tile t+2 are issued there and spread over the following k-steps, while the
+//     last k-step's MFMAs already run on prefetched fragments of tile t+1's first step.
+// Reduction order: channel-chunk-major, taps innermost (the 3x3 neighbourhood of a pixel row stays in L2).
+#include "sg_conv.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define SG2_IDENT_OUT 32
+
+struct SgIgemm2Args {
+  const u16* a;        // bf16 activation operand, NHWC [Bn, Ha, Wa, Ca], Ca % 64 == 0
+  const u16* w;        // packed bf16 filter [tap][N][Ca] (sg_pack_filter_bf16), N % 256 == 0
+  float* out;          // fp32 NHWC [Bn, Ho, Wo, N]
+  u16* out16;          // nullable: bf16 copy of the result (after bias / mask / ReLU), same layout
+  const float* bias;
+  const float* bias2;
+  const float* mask;   // nullable, fp32, same shape as out: result := 0 where mask <= 0
+  int Bn, Ha, Wa, Ca;
+  int Hg, Wg, a_sy, a_sx;
+  int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
+  int ntaps, flags;
+  int full_tiles, tail_split, n_tiles_total;
+  SgTap taps[SG_MAX_TAPS];   // w_off in elements of the packed filter
+};
+
+__device__ __attribute__((aligned(256))) unsigned int sg2_zero_page[64];      // 256 bytes of zeros (never written)
+
+__device__ __forceinline__ int sg2_xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 -> bf16 (round to nearest even), optional ReLU, optional per-row factor (row = `rowlen` consecutive elements:
+// the per-sample factors of the shared backward sweep applied while the weight-grad operand is converted)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cvt_bf16(const float* __restrict__ x, u16* __restrict__ out, long n8, int relu,
+                                                  const float* __restrict__ rowscale, long rowlen) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+    float4 v0 = reinterpret_cast<const float4*>(x)[2 * e], v1 = reinterpret_cast<const float4*>(x)[2 * e + 1];
+    if (rowscale) {
+      const float s = rowscale[(8 * e) / rowlen];
+      v0.x *= s; v0.y *= s; v0.z *= s; v0.w *= s; v1.x *= s; v1.y *= s; v1.z *= s; v1.w *= s;
+    }
+    if (relu) {
+      v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+      v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+    }
+    bf16x8 h;
+    h[0] = (__bf16)v0.x; h[1] = (__bf16)v0.y; h[2] = (__bf16)v0.z; h[3] = (__bf16)v0.w;
+    h[4] = (__bf16)v1.x; h[5] = (__bf16)v1.y; h[6] = (__bf16)v1.z; h[7] = (__bf16)v1.w;
+    reinterpret_cast<bf16x8*>(out)[e] = h;
+  }
+}
+
+// x fp32 [n] -> out bf16 [n], n % 8 == 0; rowscale (nullable) [n / rowlen], rowlen % 8 == 0
+extern "C" int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream) {
+  if (!x || !out || n < 0 || (n & 7) || (rowscale && (rowlen <= 0 || (rowlen & 7)))) return SG_ERR_ARG;
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, n / 8, relu, rowscale, rowlen);
+  return sg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int SG2_BM = 256, SG2_BN = 256, SG2_BK = 64;
+constexpr int SG2_TILE = SG2_BM * SG2_BK * 2;                 // bytes of one operand tile (32 KB; BM == BN)
+constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A stage 1 | B stage 0 | B stage 1
+
+__global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int BM = SG2_BM, BN = SG2_BN, BK = SG2_BK;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves, wave tile 128 x 64
+
+  const int M = p.Bn * p.Hg * p.Wg;
+  const int HW = p.Hg * p.Wg;
+  const int n_tiles = p.N / BN;
+  int wg, split, nsplit;
+  if ((int)blockIdx.x < p.full_tiles) {
+    wg = sg2_xcd_remap(blockIdx.x, p.full_tiles);
+    split = 0;
+    nsplit = 1;
+  } else {
+    const int tail_tiles = p.n_tiles_total - p.full_tiles;
+    const int u = sg2_xcd_remap(blockIdx.x - p.full_tiles, tail_tiles * p.tail_split);
+    nsplit = p.tail_split;
+    split = u / tail_tiles;
+    wg = p.full_tiles + (u - split * tail_tiles);
+  }
+  const int m0 = (wg / n_tiles) * BM;
+  const int n0 = (wg % n_tiles) * BN;
+  const int kchunks = p.Ca / BK;
+  const int KT_all = p.ntaps * kchunks;
+  const int kt_begin = (int)(((long)KT_all * split) / nsplit);
+  const int KT = (int)(((long)KT_all * (split + 1)) / nsplit) - kt_begin;
+
+  // ---- DMA lane roles: instruction i of wave w covers tile rows (8 i + w) * 8 .. + 7; lane -> row (l >> 3), slot (l & 7)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(sg2_zero_page) + 16 * lslot;
+  unsigned a_off[4], a_msk[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (8 * i + wave) * 8 + lrow;
+    const int chunk = lslot ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HW;
+    const int rem = mm - b * HW;
+    const int yg = rem / p.Wg;
+    const int xg = rem - yg * p.Wg;
+    const int y = yg * p.a_sy, x = xg * p.a_sx;
+    a_off[i] = 2u * (unsigned)(((b * p.Ha + y) * p.Wa + x) * p.Ca) + 16u * chunk;
+    unsigned mk = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy = y + p.taps[t].dy, ix = x + p.taps[t].dx;
+      if (ok && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) mk |= 1u << t;
+    }
+    a_msk[i] = mk;
+    b_off[i] = 2u * (unsigned)((n0 + r) * p.Ca) + 16u * chunk;
+  }
+  // tap constants live in the lanes of two VGPRs (lane t = tap t): {byte offset of the tap in the activation, byte offset
+  // of the tap's slab in the packed filter}; v_readlane with the (uniform) tap cursor fetches them without a memory access
+  int tab_a = 0, tab_w = 0;
+  if (lane < p.ntaps) {
+    tab_a = 2 * (p.taps[lane].dy * p.Wa + p.taps[lane].dx) * p.Ca;
+    tab_w = 2 * p.taps[lane].w_off;
+  }
+  int lt = kt_begin % p.ntaps, lc0 = (kt_begin / p.ntaps) * BK;         // cursor of the tile being loaded
+  int lidx = 0;                                                          // its index in this workgroup's reduction range
+  int cur_a = 0, cur_w = 0;                                              // its tap / channel-chunk byte offsets (uniform)
+  unsigned cur_bit = 0;
+  bool cur_live = true;
+  // Tiles past the end of the range ("phantom" tiles) are loaded like any other, from the zero page: the k-loop below
+  // has no tile-count dependent branch (a branch makes hipcc fall back from counted lgkmcnt waits to lgkmcnt(0), which
+  // serialises the fragment prefetch), and a phantom tile's products are zeros.
+  auto set_cursor = [&]() {
+    cur_live = lidx < KT;
+    cur_a = __builtin_amdgcn_readlane(tab_a, lt) + 2 * lc0;
+    cur_w = __builtin_amdgcn_readlane(tab_w, lt) + 2 * lc0;
+    cur_bit = cur_live ? (1u << lt) : 0u;
+  };
+  set_cursor();
+  auto advance = [&]() {
+    ++lidx;
+    ++lt;
+    const bool wrap = lt >= p.ntaps;
+    lt = wrap ? 0 : lt;
+    lc0 += wrap ? BK : 0;
+    set_cursor();
+  };
+  const unsigned long long a_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.a);
+  const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
+  const unsigned long long w_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.w);
+  // part q (0..3) of the tile at the cursor into stage `st`: A rows of instruction q and B rows of instruction q
+  auto issue_part = [&](int st, int q) {
+    const bool ok = (a_msk[q] & cur_bit) != 0;
+    const unsigned long long pa = a_base64 + (unsigned long long)(a_off[q] + (unsigned)cur_a);
+    const unsigned lo = ok ? (unsigned)pa : (unsigned)z_base64;
+    const unsigned hi = ok ? (unsigned)(pa >> 32) : (unsigned)(z_base64 >> 32);
+    const unsigned char* src_a = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    const unsigned long long pb = cur_live ? w_base64 + (unsigned long long)(b_off[q] + (unsigned)cur_w) : z_base64;
+    const unsigned char* src_b = reinterpret_cast<const unsigned char*>((uintptr_t)pb);
+    unsigned char* dst_a = smem + st * SG2_TILE + (8 * q + wave) * 1024;
+    unsigned char* dst_b = dst_a + 2 * SG2_TILE;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a, (__attribute__((address_space(3))) void*)dst_a, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_b, (__attribute__((address_space(3))) void*)dst_b, 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment addressing: row (l & 31) of a 32-row group, k-chunk 2 s + (l >> 5) of step s, swizzled slot
+  const int frow = lane & 31, khalf = lane >> 5, swz = (frow >> 1) & 7;
+  // Fragment reads are inline asm with hand-counted s_waitcnt: hipcc treats global_load_lds as a FLAT access that may touch
+  // LDS, and from the first one on turns every counted lgkmcnt(N) into lgkmcnt(0) -- which would wait for the NEXT step's
+  // fragment reads before the current step's MFMAs (seen in the ISA).  The asm reads are invisible to that pass; the
+  // sched_barriers keep the (register-only) MFMAs behind the waits (guide section 5.4 rule 18).
+  // Per-lane LDS byte addresses of the four k-steps' chunks in row `frow` of the wave's first 32-row group; the 32-row
+  // group (i, j) and the stage are immediates of the ds_read.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned a_addr[4], b_addr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const unsigned ko = 16u * (unsigned)((2 * s + khalf) ^ swz);
+    a_addr[s] = lds0 + (unsigned)((wm * 128 + frow) * 128) + ko;
+    b_addr[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+  }
+  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
+  const short rfloor = relu_in ? (short)0 : (short)0x8000;
+  const s16x8 rfloor8 = {rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor};
+
+  v4i af[2][4], bfr[2][2];
+#define SG2_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  // (macros, not lambdas: the stage / step / slot must reach the asm as literal constants)
+#define SG2_READ_FRAGS(st, s, slot)                                   \
+  do {                                                                \
+    SG2_DSR(af[slot][0], a_addr[s], (st) * SG2_TILE + 0 * 4096);      \
+    SG2_DSR(af[slot][1], a_addr[s], (st) * SG2_TILE + 1 * 4096);      \
+    SG2_DSR(af[slot][2], a_addr[s], (st) * SG2_TILE + 2 * 4096);      \
+    SG2_DSR(af[slot][3], a_addr[s], (st) * SG2_TILE + 3 * 4096);      \
+    SG2_DSR(bfr[slot][0], b_addr[s], (st) * SG2_TILE + 0 * 4096);     \
+    SG2_DSR(bfr[slot][1], b_addr[s], (st) * SG2_TILE + 1 * 4096);     \
+  } while (0)
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, af[slot][i]), rfloor8));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bfr[slot][j]), acc[i][j], 0, 0, 0);
+    }
+  };
+#define SG2_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_part(0, q);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_part(1, 0);
+    issue_part(1, 1);
+    SG2_READ_FRAGS(0, 0, 0);
+  }
+
+  // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, parts 0-1 of tile t+1 issued.
+  // After step 2: tile t+1 has landed (this wave's DMAs; the barrier extends that to every wave's) and every wave has its
+  // last fragments of stage `st` in registers, so stage `st` is free for tile t+2.
+#define SG2_K_TILE(st, sn)                                                                                   \
+  do {                                                                                                       \
+    SG2_READ_FRAGS(st, 1, 1);                                                                                \
+    issue_part(sn, 2);                                                                                       \
+    SG2_WAIT_LGKM(6); /* slot 0 is in; the six reads of step 1 stay in flight under the MFMAs */             \
+    mma(0);                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    SG2_READ_FRAGS(st, 2, 0);                                                                                \
+    issue_part(sn, 3);                                                                                       \
+    advance();                                                                                               \
+    SG2_WAIT_LGKM(6);                                                                                        \
+    mma(1);                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    SG2_READ_FRAGS(st, 3, 1);                                                                                \
+    SG2_WAIT_LGKM(6);                                                                                        \
+    mma(0);                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    issue_part(st, 0);                                                                                       \
+    issue_part(st, 1);                                                                                       \
+    SG2_READ_FRAGS(sn, 0, 0);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    mma(1);                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+  } while (0)
+  for (int kt = 0; kt < KT; kt += 2) {          // two tiles per iteration: the stage index is a compile-time constant;
+    SG2_K_TILE(0, 1);                           // with KT odd the last tile of the last iteration is a phantom tile
+    SG2_K_TILE(1, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the phantom tiles' DMAs and fragment reads
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue (fp32): accumulator row = pixel, lane = channel
+  const bool accum = (p.flags & SG_ACCUM) != 0;
+  const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
+  const bool ident = (p.flags & SG2_IDENT_OUT) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    float bsum = 0.f;
+    if (p.bias && split == 0) bsum += p.bias[n];
+    if (p.bias2 && split == 0) bsum += p.bias2[n];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        size_t idx;
+        if (ident) {
+          idx = (size_t)m * p.N + n;
+        } else {
+          const int b = m / HW;
+          const int rem = m - b * HW;
+          const int yg = rem / p.Wg;
+          const int xg = rem - yg * p.Wg;
+          idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
+        }
+        float v = acc[i][j][r] + bsum;
+        if (p.mask && p.mask[idx] <= 0.f) v = 0.f;
+        if (nsplit > 1) {
+          atomicAdd(p.out + idx, v);
+          continue;
+        }
+        if (accum) v += p.out[idx];
+        if (relu_out) v = fmaxf(v, 0.f);
+        p.out[idx] = v;
+        if (p.out16) reinterpret_cast<__bf16*>(p.out16)[idx] = (__bf16)v;
+      }
+    }
+  }
+}
+
+static int g2_split_override = -1;
+extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
+
+// -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
+// rows of reduction-split tiles are summed by atomics: their bf16 copy needs a convert pass afterwards)
+static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done) {
+  SgIgemm2Args a = a_in;
+  if ((a.Ca % SG2_BK) || (a.N % SG2_BN) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
+  const long a_bytes = 2L * a.Bn * a.Ha * a.Wa * a.Ca;
+  long w_elems = 0;
+  for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
+  w_elems += (long)a.N * a.Ca;
+  if (a_bytes >= (1L << 32) - 64 || 2 * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
+  if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
+  const long M = (long)a.Bn * a.Hg * a.Wg;
+  const int n_tiles = a.N / SG2_BN;
+  const int tiles = sg_cdiv(M, SG2_BM) * n_tiles;
+  if (tiles <= 0) return SG_OK;
+  const int KT_all = a.ntaps * (a.Ca / SG2_BK);
+  // one workgroup per CU: a launch of T equal tiles takes ceil(T / 256) tile-times; the tiles beyond the last multiple of
+  // 256 (all of them when T < 512) are cut along the reduction and summed with float atomics (model of launch_cfg in
+  // conv_igemm.hip at OCC = 1)
+  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT));
+  constexpr int CUS = 256;
+  int full = tiles, nsplit = 1;
+  if (can_split && g2_split_override != 1 && KT_all >= 8) {
+    const int rem = tiles % CUS;
+    if (g2_split_override > 1) {
+      full = 0;
+      nsplit = g2_split_override < KT_all ? g2_split_override : 1;
+    } else if (rem > 0) {
+      const int full_c = tiles < 2 * CUS ? 0 : (tiles - rem) / n_tiles * n_tiles;
+      const int tail = tiles - full_c;
+      auto cost = [&](int sp) { return (double)((tail * sp + CUS - 1) / CUS) / sp * (1.0 + 0.03 * (sp - 1)); };
+      int best = 1;
+      double best_cost = cost(1);
+      const int sp_max = KT_all / 4 < 16 ? KT_all / 4 : 16;
+      for (int sp = 2; sp <= sp_max; ++sp) {
+        const double c = cost(sp);
+        if (c < 0.97 * best_cost) { best = sp; best_cost = c; }
+      }
+      if (best > 1) { full = full_c; nsplit = best; }
+    }
+  }
+  const long row0 = nsplit > 1 ? (long)(full / n_tiles) * SG2_BM : M;
+  if (nsplit > 1 && !(a.flags & SG_ACCUM)) {
+    if (hipMemsetAsync(a.out + (size_t)row0 * a.N, 0, sizeof(float) * (size_t)(M - row0) * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  }
+  a.full_tiles = full;
+  a.tail_split = nsplit;
+  a.n_tiles_total = tiles;
+  static bool attr_done = false;
+  constexpr int LDS_BYTES = SG2_LDS;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return SG_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_igemm_bf16v2_kernel, dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
+  return sg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI (include/scrabble_hip.h).  Contracts of sg_conv2d_fwd / sg_conv2d_bwd_data with
+//   x16 / dy16 : the activation operand as a bf16 NHWC tensor (sg_cvt_bf16 or a previous launch's y16 / dx16);
+//   wp         : the packed bf16 filter of sg_pack_filter_bf16 (forward: [tap][Cout][Cin], data-grad: [tap][Cin][Cout]);
+//   y16 / dx16 : nullable; receives the bf16 copy of the fp32 result.
+// Shapes that do not qualify (reduction channels % 64, output channels % 256) return SG_ERR_UNSUPPORTED: the caller
+// falls back to sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor.
+// ------------------------------------------------------------------------------------------
+static int finish_twin(const SgIgemm2Args& a, long rows_done, hipStream_t s) {
+  if (!a.out16) return SG_OK;
+  const long M = (long)a.Bn * a.Ho * a.Wo;
+  if (rows_done >= M) return SG_OK;
+  const long n = (M - rows_done) * a.N;
+  hipLaunchKernelGGL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, s, a.out + (size_t)rows_done * a.N,
+                     a.out16 + (size_t)rows_done * a.N, n / 8, 0, (const float*)nullptr, 8L);
+  return sg_launch_status();
+}
+
+extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
+                                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!x16 || !wp_fwd || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)x16; a.w = (const u16*)wp_fwd; a.out = y; a.out16 = (u16*)y16; a.bias = bias; a.bias2 = bias2; a.mask = nullptr;
+  a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  long done = 0;
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done);
+  return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
+}
+
+extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, float* dx, void* dx16, int B, int H,
+                                         int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!dy16 || !wp_bwd || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)dy16; a.w = (const u16*)wp_bwd; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask;
+  a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
+  long done = 0;
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done);
+  return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
+}
+
+// ==========================================================================================================
+// Weight gradient, second generation:  dW_t[c][n] += sum_m P[pix(m) + tap_t][c] * Q[m][n]
+//   P = the layer input (bf16 NHWC [B,H,W,Cp]), Q = the output gradient (bf16 NHWC [B,H,W,Cq], already multiplied by the
+//   per-sample factors of the shared sweep where those apply: sg_cvt_bf16's rowscale), stride-1 convolutions only.
+// The reduction index (pixels) is the SLOW index of both operands in memory, the MFMA wants it fastest in each lane's
+// fragment.  Round 1 transposed in registers (8x4 blocks through VGPRs and ds_write).  Here the tiles go global -> LDS by
+// DMA exactly as they lie in memory ([64 pixels][256 channels], 512 B per pixel, as two 128-channel sub-tiles with
+// 256-byte rows) and the transposition is done by the LDS read itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group
+// column i of a 4-row x 16-column block, i.e. four consecutive pixels of one channel -- two of them make the 8-pixel
+// fragment of v_mfma_f32_32x32x16_bf16 for BOTH operands.  Bank swizzle (guide T10, image (b)): 16-byte chunk ch of row r
+// lives in slot ch ^ (((r & 3) << 2) | ((r >> 2) & 3)); the DMA applies it on the source side.
+// Workgroup = one (tap, 256-channel c-tile, 256-channel n-tile) x one chunk of pixels; 8 waves (2 x 4), wave tile 128 x 64
+// -> 12 transposed reads per 8 MFMAs; same two-stage pipeline and phantom-tile loop as sg_igemm_bf16v2_kernel.  Partial
+// sums of the pixel chunks meet in dW through float atomics (one 128-byte row segment per half-wave).
+struct SgWgrad2Args {
+  const u16* p;        // bf16 [Bn, H, W, Cp]
+  const u16* q;        // bf16 [Bn, H, W, Cq]
+  float* dw;           // per tap a [Cp x Cq] row-major fp32 matrix at dw + taps[t].w_off
+  int Bn, H, W, Cp, Cq;
+  int ntaps, flags;    // SG_RELU_IN applies to P
+  int mchunk;          // pixels per workgroup (multiple of 64)
+  int c_tiles, n_tiles, nchunks;
+  SgTap taps[SG_MAX_TAPS];
+};
+
+__global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;              // 2 (c) x 4 (n) waves, wave tile 128 x 64
+  const long M = (long)p.Bn * p.H * p.W;
+  // block -> (pixel chunk, combo): the combos of one chunk are adjacent (they re-read the same pixels from L2 / MALL)
+  const int combos = p.ntaps * p.c_tiles * p.n_tiles;
+  const int chunk = blockIdx.x / combos;
+  int combo = blockIdx.x - chunk * combos;
+  const int tap = combo / (p.c_tiles * p.n_tiles);
+  combo -= tap * p.c_tiles * p.n_tiles;
+  const int c0 = (combo / p.n_tiles) * 256, n0 = (combo % p.n_tiles) * 256;
+  const long m_begin = (long)chunk * p.mchunk;
+  const long m_end = m_begin + p.mchunk < M ? m_begin + p.mchunk : M;
+  const int KT = (int)((m_end - m_begin + 63) / 64);
+  const int tdy = p.taps[tap].dy, tdx = p.taps[tap].dx;
+
+  // ---- DMA lane roles.  Instruction ii = 8 i + wave (i = 0..3) moves sub-tile (ii & 1), rows 4 (ii >> 1) .. + 3:
+  //      lane -> row (l >> 4) of the four, slot (l & 15); it fetches chunk slot ^ g(row) of its pixel's 128-channel half
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(sg2_zero_page) + 16 * (lane & 15);
+  int ry[4], rx[4];            // (y, x) cursor of the pixel this lane loads for instruction i in the CURRENT load tile
+  long rm[4];                  // its pixel index
+  unsigned csw[4];             // byte offset of its (swizzled) chunk inside the pixel's channel vector, before the c0 / n0 tile offset
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ii = 8 * i + wave;
+    const int sub = ii & 1, row = 4 * (ii >> 1) + (lane >> 4);
+    const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+    csw[i] = 2u * (unsigned)(sub * 128) + 16u * (unsigned)((lane & 15) ^ g);
+    const long m = m_begin + row;
+    rm[i] = m;
+    const long mm = m < M ? m : 0;
+    const int rem = (int)(mm % HW);
+    ry[i] = rem / p.W;
+    rx[i] = rem - ry[i] * p.W;
+  }
+  const int adv_y = (64 % HW) / p.W, adv_x = (64 % HW) % p.W;       // cursor advance of 64 pixels (within one image plane)
+  const int Hh = p.H;
+  const unsigned long long p_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 2ull * (unsigned)c0;
+  const unsigned long long q_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 2ull * (unsigned)n0;
+  const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
+  const long tap_shift = (long)tdy * p.W + tdx;                      // pixel shift of the tap (may be negative)
+  // part i of the load tile at the cursors into stage `st`, then advance cursor i by one tile (64 pixels)
+  auto issue_part = [&](int st, int i) {
+    const bool live = rm[i] < m_end;
+    const int sy = ry[i] + tdy, sx = rx[i] + tdx;
+    const bool okp = live && sy >= 0 && sy < Hh && sx >= 0 && sx < p.W;
+    const unsigned long long pa = p_base64 + (unsigned long long)((rm[i] + tap_shift) * p.Cp) * 2ull + csw[i];
+    const unsigned long long qa = q_base64 + (unsigned long long)(rm[i] * p.Cq) * 2ull + csw[i];
+    const unsigned plo = okp ? (unsigned)pa : (unsigned)z_base64, phi = okp ? (unsigned)(pa >> 32) : (unsigned)(z_base64 >> 32);
+    const unsigned qlo = live ? (unsigned)qa : (unsigned)z_base64, qhi = live ? (unsigned)(qa >> 32) : (unsigned)(z_base64 >> 32);
+    const unsigned char* src_p = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)phi << 32) | plo));
+    const unsigned char* src_q = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)qhi << 32) | qlo));
+    const int ii = 8 * i + wave;
+    unsigned char* dst_p = smem + st * SG2_TILE + (ii & 1) * 16384 + (ii >> 1) * 1024;
+    unsigned char* dst_q = dst_p + 2 * SG2_TILE;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_p, (__attribute__((address_space(3))) void*)dst_p, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_q, (__attribute__((address_space(3))) void*)dst_q, 16, 0, 0);
+    // advance this cursor by 64 pixels
+    rm[i] += 64;
+    rx[i] += adv_x;
+    const int wx = rx[i] >= p.W ? 1 : 0;
+    rx[i] -= wx * p.W;
+    ry[i] += adv_y + wx;
+    ry[i] -= ry[i] >= Hh ? Hh : 0;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- transposed fragment reads: lane = 16 grp4 + 4 q + pp; h = l >> 5 (pixel half of the k-step), grp = (l >> 4) & 1
+  //      (16-channel half of a 32-channel group); read u (0,1) covers pixels 16 ks + 8 h + 4 u + q
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int q4 = (lane >> 2) & 3, pp = lane & 3, grp = (lane >> 4) & 1, h = lane >> 5;
+  unsigned pa_addr[4][2], qb_addr[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 8 * h + 4 * u + q4;                       // + 16 ks (an immediate)
+    const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = 4 * i + 2 * grp + (pp >> 1);
+      pa_addr[i][u] = lds0 + (unsigned)(wm * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch = 8 * (wn & 1) + 4 * j + 2 * grp + (pp >> 1);
+      qb_addr[j][u] = lds0 + (unsigned)(2 * SG2_TILE + (wn >> 1) * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+    }
+  }
+  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
+  const short rfloor = relu_in ? (short)0 : (short)0x8000;
+  const s16x8 rfloor8 = {rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor};
+  v2i af[2][4][2], bfr[2][2][2];          // [slot][group][u]
+#define SGW_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define SGW_READ_FRAGS(st, ks, slot)                                                  \
+  do {                                                                                \
+    SGW_TR(af[slot][0][0], pa_addr[0][0], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][0][1], pa_addr[0][1], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][1][0], pa_addr[1][0], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][1][1], pa_addr[1][1], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][2][0], pa_addr[2][0], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][2][1], pa_addr[2][1], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][3][0], pa_addr[3][0], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(af[slot][3][1], pa_addr[3][1], (st) * SG2_TILE + (ks) * 4096);             \
+    SGW_TR(bfr[slot][0][0], qb_addr[0][0], (st) * SG2_TILE + (ks) * 4096);            \
+    SGW_TR(bfr[slot][0][1], qb_addr[0][1], (st) * SG2_TILE + (ks) * 4096);            \
+    SGW_TR(bfr[slot][1][0], qb_addr[1][0], (st) * SG2_TILE + (ks) * 4096);            \
+    SGW_TR(bfr[slot][1][1], qb_addr[1][1], (st) * SG2_TILE + (ks) * 4096);            \
+  } while (0)
+  auto mma = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const v4i a4 = {af[slot][i][0][0], af[slot][i][0][1], af[slot][i][1][0], af[slot][i][1][1]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a4), rfloor8));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const v4i b4 = {bfr[slot][j][0][0], bfr[slot][j][0][1], bfr[slot][j][1][0], bfr[slot][j][1][1]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+#define SGW_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_part(1, 0);
+    issue_part(1, 1);
+    SGW_READ_FRAGS(0, 0, 0);
+  }
+#define SGW_K_TILE(st, sn)                                         \
+  do {                                                             \
+    SGW_READ_FRAGS(st, 1, 1);                                      \
+    issue_part(sn, 2);                                             \
+    SGW_WAIT_LGKM(12);                                             \
+    mma(0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    SGW_READ_FRAGS(st, 2, 0);                                      \
+    issue_part(sn, 3);                                             \
+    SGW_WAIT_LGKM(12);                                             \
+    mma(1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    SGW_READ_FRAGS(st, 3, 1);                                      \
+    SGW_WAIT_LGKM(12);                                             \
+    mma(0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                                  \
+    issue_part(st, 0);                                             \
+    issue_part(st, 1);                                             \
+    SGW_READ_FRAGS(sn, 0, 0);                                      \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    mma(1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+  for (int kt = 0; kt < KT; kt += 2) {
+    SGW_K_TILE(0, 1);
+    SGW_K_TILE(1, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: accumulator row = c, lane = n; dW[c][n] += (atomics: nchunks adders per address)
+  float* dwt = p.dw + p.taps[tap].w_off;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicAdd(dwt + (size_t)c * p.Cq + n, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// x16 bf16 [B,H,W,Cin], dy16 bf16 [B,H,W,Cout] (per-sample factors already applied), dw fp32 [kh,kw,Cin,Cout] +=.
+// SAME stride-1 convolutions with Cin % 256 == 0 and Cout % 256 == 0, else SG_ERR_UNSUPPORTED (caller: sg_conv2d_bwd_weight).
+extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
+                                           int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!x16 || !dy16 || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (!pad_same && (kh != 1 || kw != 1)) return SG_ERR_UNSUPPORTED;
+  if ((Cin % 256) || (Cout % 256)) return SG_ERR_UNSUPPORTED;
+  const long M = (long)B * H * W;
+  if (M <= 0) return SG_OK;
+  if (2L * M * Cin >= (1L << 40) || 2L * M * Cout >= (1L << 40)) return SG_ERR_UNSUPPORTED;
+  SgWgrad2Args a{};
+  a.p = (const u16*)x16; a.q = (const u16*)dy16; a.dw = dw;
+  a.Bn = B; a.H = H; a.W = W; a.Cp = Cin; a.Cq = Cout; a.ntaps = kh * kw; a.flags = flags;
+  const int ph = kh / 2, pw = kw / 2;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  a.c_tiles = Cin / 256;
+  a.n_tiles = Cout / 256;
+  const int combos = a.ntaps * a.c_tiles * a.n_tiles;
+  // ~8 workgroups per CU in whole rounds of the 256 CUs (one workgroup per CU at a time), at least 8 k-tiles each
+  const long max_chunks = (M + 511) / 512;
+  long nchunks = 1;
+  double best = 1e30;
+  for (long c = (1024 + combos - 1) / combos; c <= (3072 + combos - 1) / combos; ++c) {
+    const long cc = c < 1 ? 1 : (c > max_chunks ? max_chunks : c);
+    const long Wg = combos * cc;
+    const double loss = (double)((Wg + 255) / 256) * 256.0 / (double)Wg * (1.0 + 0.004 * cc);
+    if (loss < best) { best = loss; nchunks = cc; }
+  }
+  long mchunk = (M + nchunks - 1) / nchunks;
+  mchunk = (mchunk + 63) / 64 * 64;
+  nchunks = (M + mchunk - 1) / mchunk;
+  a.mchunk = (int)mchunk;
+  a.nchunks = (int)nchunks;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG2_LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return SG_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_wgrad_bf16v2_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), SG2_LDS, (hipStream_t)stream, a);
+  return sg_launch_status();
+}

@@ -118,6 +118,7 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     """
     G = composite_gan.generator
     D, R, S = discriminator, recognizer, style_promoter
+    ops.new_step()                                                  # bf16 twins of the previous step's activations are released
     dev = G.device
     red = G.reducer
     nl = nl or {}

@@ -137,7 +137,7 @@ def block_down_specs(pre: str, cin: int, cout: int):
 
 def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
     p = S.p
-    c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True)          # :97-99
+    c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True, want16=True)          # :97-99
     if is_last:
         out = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])                     # :109-111
         ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True, out=out, accum=True)   # :102-104,114
@@ -157,7 +157,7 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     if want_dw:
         ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
         ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
-    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1)
+    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=True)
     if want_dw:
         ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
     if not want_dx:

@@ -199,18 +199,99 @@ def _bf16_ok(K: int, N: int) -> bool:
     return CONV_DTYPE == "bf16" and K % 8 == 0 and N > 32 and K > 1
 
 
+# ---- bf16 twins (second-generation bf16 path, conv_bf16v2.hip) ---------------------------------------------------
+# In bf16 mode the large convolutions read their activation operand as a bf16 NHWC tensor.  A "twin" is the bf16 copy of
+# an fp32 activation: written by the producing conv's epilogue (y16 / dx16) or by sg_cvt_bf16 on first use, and found
+# again through this registry (keyed by the fp32 tensor's storage; a batch slice of a registered tensor maps to the
+# same slice of its twin).  An entry holds a reference to the fp32 tensor, so its storage cannot be recycled while the
+# entry lives; kernels that write INTO an existing tensor drop its entry (_touch).  new_step() empties the registry.
+USE_V2 = _os.environ.get("SG_BF16_V2", "1") == "1"
+_TWINS = {}
+
+
+def new_step() -> None:
+    _TWINS.clear()
+
+
+def _touch(t) -> None:
+    if t is not None and _TWINS:
+        k = t.untyped_storage().data_ptr()
+        _TWINS.pop(k, None)
+        for kk in [kk for kk in _TWINS if isinstance(kk, tuple) and kk[0] == k]:
+            del _TWINS[kk]
+
+
+def bf16_scaled(t: torch.Tensor, rowscale: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of rowscale[b] * t[b] (the weight-grad operand of a shared backward sweep); one conversion per (t, rowscale)."""
+    key = (t.untyped_storage().data_ptr(), rowscale.data_ptr(), t.storage_offset(), t.numel())
+    e = _TWINS.get(key)
+    if e is None:
+        e = (t, rowscale, cvt_bf16(t, rowscale=rowscale))
+        _TWINS[key] = e
+    return e[2]
+
+
+def _twin_put(t: torch.Tensor, t16: torch.Tensor) -> None:
+    if t.storage_offset() != 0 or t.numel() * 4 != t.untyped_storage().nbytes():
+        return
+    if len(_TWINS) > 512:
+        _TWINS.clear()
+    _TWINS[t.untyped_storage().data_ptr()] = (t, t16.view(-1))
+
+
+def _twin_get(t: torch.Tensor):
+    e = _TWINS.get(t.untyped_storage().data_ptr())
+    if e is None:
+        return None
+    off = t.storage_offset()
+    return e[1][off:off + t.numel()].view(t.shape)
+
+
+def cvt_bf16(t: torch.Tensor, relu=False, rowscale=None) -> torch.Tensor:
+    """fp32 -> bf16 copy (sg_cvt_bf16); rowscale [B] multiplies sample b first."""
+    _chk(t, rowscale)
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    n = t.numel()
+    assert n % 8 == 0
+    with _hbm("cvt_bf16", t, out):
+        call("sg_cvt_bf16", _p(t), out.data_ptr(), n, int(relu), _p(rowscale), (n // rowscale.numel()) if rowscale is not None else 8, _stream())
+    return out
+
+
+def bf16_of(t: torch.Tensor) -> torch.Tensor:
+    """The bf16 twin of an fp32 activation (made on first use)."""
+    t16 = _twin_get(t)
+    if t16 is None:
+        t16 = cvt_bf16(t)
+        _twin_put(t, t16)
+    return t16
+
+
+def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
+    return USE_V2 and CONV_DTYPE == "bf16" and K % 64 == 0 and N % 256 == 0 and (same or (kh == 1 and kw == 1))
+
+
 def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,
-               out=None, accum=False):
+               out=None, accum=False, want16=False):
+    """want16 (bf16 mode): also keep a bf16 twin of the result for the next conv (written by the kernel's epilogue)."""
     _chk(x, w, bias, bias2, out)
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = w.shape
     assert wc == Cin, (w.shape, x.shape)
     Ho, Wo = (H, W) if same else (H - kh + 1, W - kw + 1)
+    _touch(out)
     if out is None:
         out = empty(B, Ho, Wo, Cout, like=x)
     with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
-        if _bf16_ok(Cin, Cout) and not tanh_out:
+        if _v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+            x16 = bf16_of(x)
+            y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            call("sg_conv2d_fwd_bf16v2", x16.data_ptr(), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out),
+                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
+            if y16 is not None:
+                _twin_put(out, y16)
+        elif _bf16_ok(Cin, Cout) and not tanh_out:
             call("sg_conv2d_fwd_bf16", _p(x), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout,
                  kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
         else:
@@ -219,17 +300,25 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     return out
 
 
-def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=None, accum=False):
+def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=None, accum=False, want16=False):
     _chk(dy, w, mask, out)
     B = dy.shape[0]
     H, W = in_hw
     kh, kw, Cin, Cout = w.shape
     assert dy.shape[3] == Cout
+    _touch(out)
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
     with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
-        if _bf16_ok(Cout, Cin):
+        if _v2_ok(Cout, Cin, kh, kw, same):
+            dy16 = bf16_of(dy)
+            dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            call("sg_conv2d_bwd_data_bf16v2", dy16.data_ptr(), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out),
+                 None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
+            if dx16 is not None:
+                _twin_put(out, dx16)
+        elif _bf16_ok(Cout, Cin):
             call("sg_conv2d_bwd_data_bf16", _p(dy), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out), B, H, W, Cin, Cout,
                  kh, kw, int(same), _flags(accum=accum), _stream())
         elif TRANSPOSED_DGRAD_FILTERS and Cin >= 128 and Cout >= 128 and Cin % 4 == 0:
@@ -249,6 +338,17 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
+    if USE_V2 and CONV_DTYPE == "bf16" and Cin % 256 == 0 and Cout % 256 == 0 and (same or kh * kw == 1):
+        # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy; the bias
+        # gradient (fp32 sums of the scaled dy) is its own memory-bound sweep
+        x16 = bf16_of(x)
+        dy16 = bf16_of(dy) if sample_scale is None else bf16_scaled(dy, sample_scale)
+        with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
+            call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same),
+                 _flags(relu_in), _stream())
+        if db is not None:
+            bias_grad(dy if sample_scale is None else rowscale(dy, sample_scale), db)
+        return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
@@ -257,6 +357,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
     _chk(x, w, bias, bias2, out)
+    _touch(out)
     B, H, W, Cin = x.shape
     kh, kw, Cout, wc = w.shape
     assert wc == Cin
@@ -276,6 +377,7 @@ def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, a
 
 def conv2d_transpose_bwd_data(dy, w, stride=(2, 2), mask=None, out=None, accum=False):
     _chk(dy, w, mask, out)
+    _touch(out)
     kh, kw, Cout, Cin = w.shape
     sh, sw = stride
     B, Hs, Ws, _ = dy.shape
@@ -330,6 +432,7 @@ def avgpool2_bwd(dout):
 
 def add(a, b, out=None):
     _chk(a, b, out)
+    _touch(out)
     assert a.shape == b.shape
     if out is None:
         out = torch.empty_like(a)
@@ -340,6 +443,7 @@ def add(a, b, out=None):
 
 def relu_mask(dy, ref, out=None):
     _chk(dy, ref, out)
+    _touch(out)
     if out is None:
         out = torch.empty_like(dy)
     with _hbm("elementwise", dy, ref, out):
@@ -367,6 +471,7 @@ def maxpool_fwd(x, ph, pw):
 
 def maxpool_bwd(dy, idx, ph, pw, out=None, accum=False):
     _chk(dy, out)
+    _touch(out)
     B, Ho, Wo, C = dy.shape
     if out is None:
         out = empty(B, Ho * ph, Wo * pw, C, like=dy)
@@ -395,6 +500,7 @@ def gap_bwd(dout, x, relu=True):
 
 def scale_add(o, x, sigma, out=None):
     _chk(o, x, sigma, out)
+    _touch(out)
     if out is None:
         out = torch.empty_like(x)
     with _hbm("elementwise", o, x, out):
@@ -431,6 +537,7 @@ def gemm(A, B, M, N, K, lda, ldb, transA=False, transB=False, bias=None, out=Non
     """C = alpha*op(A)*op(B) + beta*C (+bias).  A_off / out_off are element offsets into A / out, which with
     lda / ldc address a column block of a wider row-major matrix (the z chunks of the generator)."""
     _chk(A, B, bias, out)
+    _touch(out)
     if out is None:
         out = empty(M, N, like=A)
     ldc = N if ldc is None else ldc

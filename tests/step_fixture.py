@@ -63,5 +63,6 @@ def calibrate(pb, loss_name="hinge", balance=False):
     s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance)
     s32, g32, w32, x32 = run_oracle(pb, torch.float32, loss_name, balance)
     err32 = {n: {k: (g32[n][k].double() - v).abs().max().item() for k, v in g64[n].items()} for n in g64}
+    l2err32 = {n: {k: (g32[n][k].double() - v).norm().item() for k, v in g64[n].items()} for n in g64}
     serr32 = [abs(a - b) for a, b in zip(s32, s64)]
-    return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item())
+    return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, l2err32=l2err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item())

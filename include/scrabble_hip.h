@@ -70,12 +70,13 @@ int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, const float* ma
  *      sg_conv2d_fwd_bf16v2 / sg_conv2d_bwd_data_bf16v2: contracts of sg_conv2d_fwd / sg_conv2d_bwd_data
  *      (resnet_ops.py:65,98,103,109) with the activation operand given as a bf16 NHWC tensor (x16 / dy16), the filter as the
  *      packed copy of sg_pack_filter_bf16, an fp32 result and, when y16 / dx16 is non-null, a bf16 copy of the result
- *      for the next launch.  SG_ERR_UNSUPPORTED unless reduction channels % 64 == 0 and output channels % 256 == 0:
+ *      for the next launch; mask16 (nullable) may replace the fp32 ReLU mask by its bf16 copy.  SG_ERR_UNSUPPORTED unless
+ *      reduction channels % 64 == 0 and output channels % 64 == 0:
  *      the caller then uses sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor. ----------------------- */
 int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream);
 int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
-int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, float* dx, void* dx16,
+int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, const void* mask16, float* dx, void* dx16,
                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 /* dw [kh,kw,Cin,Cout] (fp32) += weight gradient of the SAME stride-1 convolution from bf16 operands x16 [B,H,W,Cin] and
  * dy16 [B,H,W,Cout] (tape of d_loss / s_loss / g_final, data_utils.py:449-468; per-sample factors already folded into dy16 by
@@ -202,4 +203,18 @@ int sg_spectral_norm(const float* w, const float* u, float* out, float* workspac
 #ifdef __cplusplus
 }
 #endif
+/* ---- collective of the data-parallel step (the reference has none: BASELINE.json north_star) ----------
+ * SUM all-reduce, in place, of `n` elements of a flat device buffer over RCCL on `stream`; gradients are sums over the
+ * batch (reference data_utils.py:450,454,458,467 differentiate [B,1] targets), so ranks ADD.  comm = the ncclComm_t made by
+ * sg_rccl_comm_init_rank (or any RCCL communicator of the caller).  dtype: the enum below.  Asynchronous on `stream`.
+ * SG_ERR_UNSUPPORTED when librccl cannot be resolved or the dtype is not reducible. */
+#define SG_DTYPE_F32 0
+#define SG_DTYPE_BF16 1
+#define SG_DTYPE_FP8_E4M3 2
+#define SG_DTYPE_F64 3
+int sg_allreduce_sum(void* buf, long n, int dtype, void* comm, void* stream);
+int sg_rccl_unique_id(void* id128);                                             /* 128 bytes, created by one rank */
+int sg_rccl_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
+int sg_rccl_comm_destroy(void* comm);
+
 #endif

@@ -33,12 +33,13 @@ typedef unsigned short u16;
 
 struct SgIgemm2Args {
   const u16* a;        // bf16 activation operand, NHWC [Bn, Ha, Wa, Ca], Ca % 64 == 0
-  const u16* w;        // packed bf16 filter [tap][N][Ca] (sg_pack_filter_bf16), N % 256 == 0
+  const u16* w;        // packed bf16 filter [tap][N][Ca] (sg_pack_filter_bf16), N % 64 == 0
   float* out;          // fp32 NHWC [Bn, Ho, Wo, N]
   u16* out16;          // nullable: bf16 copy of the result (after bias / mask / ReLU), same layout
   const float* bias;
   const float* bias2;
   const float* mask;   // nullable, fp32, same shape as out: result := 0 where mask <= 0
+  const u16* mask16;   // nullable alternative to `mask`: the same tensor as bf16 (sign and zero are what matter)
   int Bn, Ha, Wa, Ca;
   int Hg, Wg, a_sy, a_sx;
   int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
@@ -87,17 +88,24 @@ extern "C" int sg_cvt_bf16(const float* x, void* out, long n, int relu, const fl
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int SG2_BM = 256, SG2_BN = 256, SG2_BK = 64;
-constexpr int SG2_TILE = SG2_BM * SG2_BK * 2;                 // bytes of one operand tile (32 KB; BM == BN)
-constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A stage 1 | B stage 0 | B stage 1
+constexpr int SG2_BM = 256, SG2_BK = 64;
+constexpr int SG2_TILE = SG2_BM * SG2_BK * 2;                 // bytes of a 256-row operand tile (32 KB)
+constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A stage 1 | B stage 0 | B stage 1 (BN = 256)
 
+// BN = 256: 2 x 4 waves, wave tile 128 x 64 (the large layers);  BN = 128: 4 x 2 waves, 64 x 64;  BN = 64: 8 x 1 waves,
+// 32 x 64 (the 64-filter layers, which are bandwidth-bound anyway).  The A tile is always 256 rows.
+template <int BN>
 __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int BM = SG2_BM, BN = SG2_BN, BK = SG2_BK;
+  constexpr int BM = SG2_BM, BK = SG2_BK;
+  constexpr int WN = BN / 64, WM = 8 / WN;              // waves along n / m
+  constexpr int TM = BM / WM / 32, TN = 2;              // 32 x 32 MFMA tiles per wave
+  constexpr int BQ = BN / 64;                           // B-tile DMA instructions per thread
+  constexpr int BTILE = BN * BK * 2;                    // bytes of the B tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves, wave tile 128 x 64
+  const int wm = wave / WN, wn = wave % WN;
 
   const int M = p.Bn * p.Hg * p.Wg;
   const int HW = p.Hg * p.Wg;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
       if (ok && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) mk |= 1u << t;
     }
     a_msk[i] = mk;
-    b_off[i] = 2u * (unsigned)((n0 + r) * p.Ca) + 16u * chunk;
+    b_off[i] = 2u * (unsigned)((n0 + (r % BN)) * p.Ca) + 16u * chunk;       // (instructions i >= BN / 64 are not issued)
   }
   // tap constants live in the lanes of two VGPRs (lane t = tap t): {byte offset of the tap in the activation, byte offset
   // of the tap's slab in the packed filter}; v_readlane with the (uniform) tap cursor fetches them without a memory access
@@ -189,16 +197,17 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     const unsigned long long pb = cur_live ? w_base64 + (unsigned long long)(b_off[q] + (unsigned)cur_w) : z_base64;
     const unsigned char* src_b = reinterpret_cast<const unsigned char*>((uintptr_t)pb);
     unsigned char* dst_a = smem + st * SG2_TILE + (8 * q + wave) * 1024;
-    unsigned char* dst_b = dst_a + 2 * SG2_TILE;
+    unsigned char* dst_b = smem + 2 * SG2_TILE + st * BTILE + (8 * q + wave) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a, (__attribute__((address_space(3))) void*)dst_a, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_b, (__attribute__((address_space(3))) void*)dst_b, 16, 0, 0);
+    if (q < BQ)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_b, (__attribute__((address_space(3))) void*)dst_b, 16, 0, 0);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const unsigned ko = 16u * (unsigned)((2 * s + khalf) ^ swz);
-    a_addr[s] = lds0 + (unsigned)((wm * 128 + frow) * 128) + ko;
+    a_addr[s] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
     b_addr[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
   }
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
@@ -226,25 +235,32 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   v4i af[2][4], bfr[2][2];
 #define SG2_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
   // (macros, not lambdas: the stage / step / slot must reach the asm as literal constants)
-#define SG2_READ_FRAGS(st, s, slot)                                   \
-  do {                                                                \
-    SG2_DSR(af[slot][0], a_addr[s], (st) * SG2_TILE + 0 * 4096);      \
-    SG2_DSR(af[slot][1], a_addr[s], (st) * SG2_TILE + 1 * 4096);      \
-    SG2_DSR(af[slot][2], a_addr[s], (st) * SG2_TILE + 2 * 4096);      \
-    SG2_DSR(af[slot][3], a_addr[s], (st) * SG2_TILE + 3 * 4096);      \
-    SG2_DSR(bfr[slot][0], b_addr[s], (st) * SG2_TILE + 0 * 4096);     \
-    SG2_DSR(bfr[slot][1], b_addr[s], (st) * SG2_TILE + 1 * 4096);     \
+#define SG2_READ_FRAGS(st, s, slot)                                                   \
+  do {                                                                                \
+    SG2_DSR(af[slot][0], a_addr[s], (st) * SG2_TILE + 0 * 4096);                      \
+    if constexpr (TM > 1) SG2_DSR(af[slot][1], a_addr[s], (st) * SG2_TILE + 1 * 4096); \
+    if constexpr (TM > 2) SG2_DSR(af[slot][2], a_addr[s], (st) * SG2_TILE + 2 * 4096); \
+    if constexpr (TM > 2) SG2_DSR(af[slot][3], a_addr[s], (st) * SG2_TILE + 3 * 4096); \
+    SG2_DSR(bfr[slot][0], b_addr[s], (st) * BTILE + 0 * 4096);                        \
+    SG2_DSR(bfr[slot][1], b_addr[s], (st) * BTILE + 1 * 4096);                        \
   } while (0)
   auto mma = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
       const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, af[slot][i]), rfloor8));
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bfr[slot][j]), acc[i][j], 0, 0, 0);
     }
   };
-#define SG2_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // wait until only the TM + TN fragment reads just issued are still in flight
+#define SG2_WAIT_FRAGS()                                                        \
+  do {                                                                          \
+    if constexpr (TM + TN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); \
+    else if constexpr (TM + TN == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); \
+    else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+  } while (0)
 
   {
 #pragma unroll
@@ -264,17 +280,17 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   do {                                                                                                       \
     SG2_READ_FRAGS(st, 1, 1);                                                                                \
     issue_part(sn, 2);                                                                                       \
-    SG2_WAIT_LGKM(6); /* slot 0 is in; the six reads of step 1 stay in flight under the MFMAs */             \
+    SG2_WAIT_FRAGS(); /* slot 0 is in; the reads of step 1 stay in flight under the MFMAs */                 \
     mma(0);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     SG2_READ_FRAGS(st, 2, 0);                                                                                \
     issue_part(sn, 3);                                                                                       \
     advance();                                                                                               \
-    SG2_WAIT_LGKM(6);                                                                                        \
+    SG2_WAIT_FRAGS();                                                                                        \
     mma(1);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     SG2_READ_FRAGS(st, 3, 1);                                                                                \
-    SG2_WAIT_LGKM(6);                                                                                        \
+    SG2_WAIT_FRAGS();                                                                                        \
     mma(0);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
@@ -298,16 +314,16 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
   const bool ident = (p.flags & SG2_IDENT_OUT) != 0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
     float bsum = 0.f;
     if (p.bias && split == 0) bsum += p.bias[n];
     if (p.bias2 && split == 0) bsum += p.bias2[n];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         const int m = m0 + row;
         if (m >= M) continue;
         size_t idx;
@@ -321,7 +337,12 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
           idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
         }
         float v = acc[i][j][r] + bsum;
-        if (p.mask && p.mask[idx] <= 0.f) v = 0.f;
+        if (p.mask16) {
+          const short mv = (short)p.mask16[idx];
+          if (mv <= 0) v = 0.f;           // bf16 <= 0  <=>  its int16 is negative or +0 (-0 = 0x8000 is negative as int16)
+        } else if (p.mask && p.mask[idx] <= 0.f) {
+          v = 0.f;
+        }
         if (nsplit > 1) {
           atomicAdd(p.out + idx, v);
           continue;
@@ -338,19 +359,10 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
 static int g2_split_override = -1;
 extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
 
-// -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
-// rows of reduction-split tiles are summed by atomics: their bf16 copy needs a convert pass afterwards)
-static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done) {
-  SgIgemm2Args a = a_in;
-  if ((a.Ca % SG2_BK) || (a.N % SG2_BN) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
-  const long a_bytes = 2L * a.Bn * a.Ha * a.Wa * a.Ca;
-  long w_elems = 0;
-  for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
-  w_elems += (long)a.N * a.Ca;
-  if (a_bytes >= (1L << 32) - 64 || 2 * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
-  if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
+template <int BN>
+static int sg2_launch_bn(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
-  const int n_tiles = a.N / SG2_BN;
+  const int n_tiles = a.N / BN;
   const int tiles = sg_cdiv(M, SG2_BM) * n_tiles;
   if (tiles <= 0) return SG_OK;
   const int KT_all = a.ntaps * (a.Ca / SG2_BK);
@@ -387,17 +399,33 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
   a.tail_split = nsplit;
   a.n_tiles_total = tiles;
   static bool attr_done = false;
-  constexpr int LDS_BYTES = SG2_LDS;
+  constexpr int LDS_BYTES = 2 * SG2_TILE + 2 * BN * SG2_BK * 2;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(sg_igemm_bf16v2_kernel, dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL(sg_igemm_bf16v2_kernel<BN>, dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   return sg_launch_status();
+}
+
+// -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
+// rows of reduction-split tiles are summed by atomics: their bf16 copy needs a convert pass afterwards)
+static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done) {
+  SgIgemm2Args a = a_in;
+  if ((a.Ca % SG2_BK) || (a.N % 64) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
+  const long a_bytes = 2L * a.Bn * a.Ha * a.Wa * a.Ca;
+  long w_elems = 0;
+  for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
+  w_elems += (long)a.N * a.Ca;
+  if (a_bytes >= (1L << 32) - 64 || 2 * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
+  if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
+  if (a.N % 256 == 0) return sg2_launch_bn<256>(a, s, twin_rows_done);
+  if (a.N % 128 == 0) return sg2_launch_bn<128>(a, s, twin_rows_done);
+  return sg2_launch_bn<64>(a, s, twin_rows_done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -405,7 +433,7 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
 //   x16 / dy16 : the activation operand as a bf16 NHWC tensor (sg_cvt_bf16 or a previous launch's y16 / dx16);
 //   wp         : the packed bf16 filter of sg_pack_filter_bf16 (forward: [tap][Cout][Cin], data-grad: [tap][Cin][Cout]);
 //   y16 / dx16 : nullable; receives the bf16 copy of the fp32 result.
-// Shapes that do not qualify (reduction channels % 64, output channels % 256) return SG_ERR_UNSUPPORTED: the caller
+// Shapes that do not qualify (reduction channels % 64, output channels % 64) return SG_ERR_UNSUPPORTED: the caller
 // falls back to sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor.
 // ------------------------------------------------------------------------------------------
 static int finish_twin(const SgIgemm2Args& a, long rows_done, hipStream_t s) {
@@ -435,13 +463,13 @@ extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const f
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
 }
 
-extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, float* dx, void* dx16, int B, int H,
-                                         int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, const void* mask16, float* dx, void* dx16,
+                                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
   if (!dy16 || !wp_bwd || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
-  a.a = (const u16*)dy16; a.w = (const u16*)wp_bwd; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask;
+  a.a = (const u16*)dy16; a.w = (const u16*)wp_bwd; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask; a.mask16 = (const u16*)mask16;
   a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
   a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
   a.ntaps = kh * kw; a.flags = flags;

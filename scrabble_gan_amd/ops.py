@@ -268,7 +268,7 @@ def bf16_of(t: torch.Tensor) -> torch.Tensor:
 
 
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
-    return USE_V2 and CONV_DTYPE == "bf16" and K % 64 == 0 and N % 256 == 0 and (same or (kh == 1 and kw == 1))
+    return USE_V2 and CONV_DTYPE == "bf16" and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
 
 
 def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,
@@ -314,7 +314,9 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
         if _v2_ok(Cout, Cin, kh, kw, same):
             dy16 = bf16_of(dy)
             dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
-            call("sg_conv2d_bwd_data_bf16v2", dy16.data_ptr(), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out),
+            m16 = None if mask is None else _twin_get(mask)          # the ReLU mask as bf16 when a twin exists (half the bytes)
+            call("sg_conv2d_bwd_data_bf16v2", dy16.data_ptr(), packed_filter(w, "bwd").data_ptr(), None if m16 is not None else _p(mask),
+                 None if m16 is None else m16.data_ptr(), _p(out),
                  None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
             if dx16 is not None:
                 _twin_put(out, dx16)

@@ -33,18 +33,15 @@ FLOP_PER_IMAGE_EXECUTED = 379.1e9 - 2 * 19.891e9   # the shared backward sweep t
 PEAK_FP32_MFMA_TF = 157.3           # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32)
 
 
-def cpu_baseline(batch=8, L=10, warmup=2, timed=5, budget_s=150.0):
-    """The oracle's train_step (torch-CPU fp32, the host cores this process may run on) on a bounded sample, with the
-    protocol of BASELINE.md section 3: bs 8, `warmup` untimed steps, median of `timed` steps.  Runs on rank 0 at N = 1
-    only, after the GPU measurement (outside the timed region).  If the host is so loaded that the protocol would not fit
-    `budget_s`, fewer timed steps are taken and the sample string says so."""
+def cpu_baseline(batch=8, L=10, warmup=2, timed=5, budget_s=100.0):
+    """The oracle's train_step (torch-CPU fp32, torch's default intra-op thread pool on this host) on a bounded sample,
+    with the protocol of BASELINE.md section 3: bs 8, `warmup` untimed steps, median of `timed` steps.  Runs on rank 0 at
+    N = 1 only, after the GPU measurement (outside the timed region).  The whole leg is bounded by `budget_s` seconds of CPU
+    work: on a slow or loaded host fewer warm-up / timed steps are taken and the sample string says how many.  One progress
+    line per step goes to stderr."""
     import statistics
     from oracle import scrabble_oracle as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
+    cores = torch.get_num_threads()
     dt = torch.float32
     g = torch.Generator().manual_seed(1)
     G, D, S, R = O.init_generator(g, dt), O.init_discriminator(g, dt), O.init_discriminator(g, dt), O.init_recognizer(g, dt)
@@ -55,19 +52,25 @@ def cpu_baseline(batch=8, L=10, warmup=2, timed=5, budget_s=150.0):
     nl = {k: O.init_nonlocal(64, g, dt) for k in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
     opt = {"G": {}, "D": {}, "R": {}, "S": {}}
     times, t_start = [], time.time()
-    for i in range(warmup + timed):
+    n_warm = warmup
+    while len(times) < n_warm + timed:
         t0 = time.time()
         O.train_step(images, labels, style, fake, G, D, S, R, nl, opt)
         times.append(time.time() - t0)
-        done_timed = len(times) - warmup
-        if done_timed >= 1 and (time.time() - t_start) + times[-1] > budget_s:
+        print("[cpu_baseline] step %d: %.2f s (%d threads)" % (len(times), times[-1], cores), file=sys.stderr, flush=True)
+        spent, per = time.time() - t_start, times[-1]
+        if len(times) == 1 and per * (warmup + 2) > budget_s:
+            n_warm = 1                                  # slow host: one warm-up only
+        if len(times) > n_warm and spent + per > budget_s:
             break
-    samples = times[warmup:] if len(times) > warmup else times[-1:]
+        if len(times) == n_warm and spent + per > budget_s and len(times) > 1:
+            break
+    samples = times[n_warm:] if len(times) > n_warm else times[-1:]
     med = statistics.median(samples)
     return {"value": batch / med, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "torch-CPU fp32 oracle train_step at bs %d, 32x160 (L = %d): %d warm-up + median of %d timed steps "
-                      "(BASELINE.md section 3); stand-in for the TF2 CPU path, TensorFlow is not installable offline"
-                      % (batch, L, min(warmup, len(times) - len(samples)), len(samples)),
+                      "(BASELINE.md section 3 asks for 2 + 5; bounded to %d s of CPU work); stand-in for the TF2 CPU path, "
+                      "TensorFlow is not installable offline" % (batch, L, len(times) - len(samples), len(samples), int(budget_s)),
             "seconds_per_step": med, "all_steps_s": [round(t, 3) for t in times]}
 
 
@@ -121,8 +124,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-steps", type=int, default=2, help="N > 1 only: extra steps after the timed region for the per-kernel HIP-event timing")
-    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16"],
-                    help="matrix-core operand type of the convolutions: f32 = the headline config c2; bf16 = config c3 (run it with --batch 256)")
+    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16", "fp8"],
+                    help="matrix-core operand type of the convolutions: f32 = the headline config c2; bf16 = config c3 (run it with --batch 256); "
+                         "fp8 = config c5, first slice (fp8 forward / data-grad, bf16 weight-grad and recognizer; --batch 512 --balance)")
+    ap.add_argument("--balance", action="store_true", help="apply_gradient_balance = 1 (config c5)")
     ap.add_argument("--bucketed", action="store_true",
                     help="config c4: one (L_r, L_f) pair per step drawn U{4..23}^2 from a stream shared by all ranks (bucket_size 23)")
     ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
@@ -155,7 +160,7 @@ def main():
     torch.cuda.set_device(dev)
     NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas
     ops.set_conv_dtype(args.conv_dtype)
-    bf16 = args.conv_dtype == "bf16"
+    bf16 = args.conv_dtype in ("bf16", "fp8")
     peak_tf = 2500.0 if bf16 else PEAK_FP32_MFMA_TF            # dense peaks of MI355X_MICROARCH.md's chip table
 
     in_dim = (32, 160, 1)
@@ -191,7 +196,7 @@ def main():
                                  B, 128, net_loss.hinge, 1, 0, words, 23, "", fake_labels=pools[L_f][2], verbose=False,
                                  sync=True if args.sync_every_step else "lazy")
         return DU.train_step(0, i, args.steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
-                             net_loss.hinge, 1, 0, words, max(10, L), "", fake_labels=fake_d, verbose=False,
+                             net_loss.hinge, 1, int(args.balance), words, max(10, L), "", fake_labels=fake_d, verbose=False,
                              sync=True if args.sync_every_step else "lazy")
 
     def fence():
@@ -258,8 +263,10 @@ def main():
         line = {
             "metric": metric, "value": value, "unit": "images/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": ("c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, fp32 tensors), hinge, disc_iters=1"
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8-e4m3 (fwd/dgrad) + bf16"}[args.conv_dtype], "data": "synthetic",
+            "config": {"workload": ("c5 (first slice): synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp8-e4m3 forward / data-grad convs of G/D/S (>= 128 channels), bf16 weight-grad and recognizer, hinge, gradient balancing " + ("on" if args.balance else "off")
+                                    if args.conv_dtype == "fp8" else
+                                    "c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, bf16 operand copies in HBM), hinge, disc_iters=1"
                                     if bf16 else "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1")
                                    % (B, L) if not args.bucketed else
                                    "c4: synthetic random_words 32x(16 L), (L_r, L_f) ~ U{4..23}^2 per step, global bs %d, %s MFMA convs" % (B, args.conv_dtype),
@@ -295,7 +302,7 @@ def main():
                                     "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
                                     "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
                                     "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
-                                    "kernel": ("sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; transposed and <= 32-filter convs stay fp32)"
+                                    "kernel": ("sg_igemm_bf16v2_kernel / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16, fp8 32x32x64 in fp8 mode; <= 32-filter convs stay fp32)"
                                                if bf16 else "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
                                     "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
                                     "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}

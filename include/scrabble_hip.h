@@ -85,6 +85,23 @@ int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float*
 int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
                                 int kh, int kw, int pad_same, int flags, void* stream);
 
+/* ---- fp8 (OCP e4m3) operands for the forward / data-grad convolutions (BASELINE config c5, first slice): per-tensor
+ *      scaling operand8 = e4m3(value * 448 / amax), amax = max|tensor| kept as a DEVICE scalar (no host sync), fp32
+ *      accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, result = sums * amax_a * amax_w / 448^2.
+ *      sg_amax_f32: amax[0] = max(amax[0], max|x|) (zero it first; n % 4 == 0).  sg_cvt_fp8: fp32 -> fp8 with that scale,
+ *      relu != 0 applies max(.,0) first (n % 8 == 0).  sg_pack_filter_fp8: as sg_pack_filter_bf16, bytes instead of bf16.
+ *      sg_conv2d_fwd_fp8 / sg_conv2d_bwd_data_fp8: contracts of the bf16v2 entry points (resnet_ops.py:98,103 call sites
+ *      of the D-shaped trunks); SG_RELU_IN is not accepted (fold it into sg_cvt_fp8); SG_ERR_UNSUPPORTED unless reduction
+ *      channels % 128 == 0 and output channels % 256 == 0. ------------------------------------------------------- */
+int sg_amax_f32(const float* x, long n, float* amax, void* stream);
+int sg_cvt_fp8(const float* x, void* out, long n, int relu, const float* amax, void* stream);
+int sg_pack_filter_fp8(const float* w, void* out, const float* amax, int taps, int K, int N, int transpose, void* stream);
+int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias, const float* bias2,
+                      float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, const void* wp8, const float* amax_w, const float* mask,
+                           const void* mask16, float* dx, void* dx16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                           int pad_same, int flags, void* stream);
+
 /* bf16 variants of the transposed convolution (w [kh,kw,Cout,Cin]): forward wp = pack(w, kh*kw, K = Cin, N = Cout,
  * transpose = 0); data-grad wp = pack(w, kh*kw, K = Cout, N = Cin, transpose = 1).  SG_ERR_UNSUPPORTED for a stride /
  * kernel combination with a tap-less parity class (1x1, stride 2) and for K % 8 != 0 or N <= 32: use the fp32 entry. */
@@ -199,10 +216,22 @@ int sg_adam_update(float* p, const float* g, float* m, float* v, long n, float l
 int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream);
 long sg_spectral_norm_workspace_floats(int K, int N);
 int sg_spectral_norm(const float* w, const float* u, float* out, float* workspace, int K, int N, int power_iteration, void* stream);
+/* backward of spectral_norm(w, u, power_iteration = 1) (arch_ops.py:107-126, no stop-gradient): dw [K,N] += d/dw given
+ * g = gradient w.r.t. the normalised weight; used by kernel_reg = 'applied' (SURVEY Appendix C-3). */
+long sg_spectral_norm_bwd_workspace_floats(int K, int N);
+int sg_spectral_norm_bwd(const float* w, const float* u, const float* g, float* dw, float* workspace, int K, int N, void* stream);
 
 #ifdef __cplusplus
 }
 #endif
+/* ---- host-pipeline helpers ------------------------------------------------------------------------------
+ * sg_normalize_u8: out[i] = (float(u8[i]) - 127.5) / 127.5, the pixel normalisation of load_prepare_data (data_utils.py:82)
+ * run on the GPU on bytes that arrived through a pinned staging buffer; bit-identical to the numpy expression; n % 16 == 0.
+ * sg_bias_add: y[m, c] += bias[c] (C % 4 == 0), the bias of the strided Conv2D layers of make_my_discriminator
+ * (net_architecture.py:425-443), whose contractions run on the transposed-convolution kernels. */
+int sg_normalize_u8(const unsigned char* u8, float* out, long n, void* stream);
+int sg_bias_add(float* y, const float* bias, long M, int C, void* stream);
+
 /* ---- collective of the data-parallel step (the reference has none: BASELINE.json north_star) ----------
  * SUM all-reduce, in place, of `n` elements of a flat device buffer over RCCL on `stream`; gradients are sums over the
  * batch (reference data_utils.py:450,454,458,467 differentiate [B,1] targets), so ranks ADD.  comm = the ncclComm_t made by

@@ -215,6 +215,40 @@ def discriminator(x: Tensor, p: Dict[str, Tensor], nl: Optional[Dict[str, Tensor
     return disc_trunk(x, p, nl, attn_blocks) @ p["dense.w"]
 
 
+def conv2d_stride2_same(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """layers.Conv2D(3x3, strides=(2,2), padding='same') on even extents (net_architecture.py:425-443; Appendix A-1):
+    pad_before 0, pad_after 1."""
+    xp = F.pad(_nchw(x), (0, 1, 0, 1))
+    return _nhwc(F.conv2d(xp, w.permute(3, 2, 0, 1).contiguous(), b, stride=2, padding=0))
+
+
+MYDISC_FILTERS = [16, 32, 64, 128]
+
+
+def my_discriminator(x: Tensor, p: Dict[str, Tensor], nl: Dict[str, Tensor]) -> Tensor:
+    """make_my_discriminator forward (net_architecture.py:417-462): 4 x [Conv2D 3x3 s2 same -> LeakyReLU(0.3)], a
+    NonLocalBlock after the second (C = 32), a second LeakyReLU after the fourth (:446), GAP, Dense(1, no bias)."""
+    net = x
+    for i in range(4):
+        net = F.leaky_relu(conv2d_stride2_same(net, p["conv%d.w" % (i + 1)], p["conv%d.b" % (i + 1)]), 0.3)
+        if i == 1:
+            net = nonlocal_block(net, nl["theta"], nl["phi"], nl["g"], nl["o"], p["NL_B1.sigma"])
+    net = F.leaky_relu(net, 0.3)
+    return net.mean(dim=(1, 2)) @ p["dense.w"]
+
+
+def init_my_discriminator(gen: torch.Generator, dtype=torch.float64, colors=1) -> Dict[str, Tensor]:
+    p: Dict[str, Tensor] = {}
+    cin = colors
+    for i, co in enumerate(MYDISC_FILTERS):
+        p["conv%d.w" % (i + 1)] = orthogonal((3, 3, cin, co), gen, dtype)
+        p["conv%d.b" % (i + 1)] = torch.zeros(co, dtype=dtype)
+        cin = co
+    p["NL_B1.sigma"] = torch.zeros((), dtype=dtype)
+    p["dense.w"] = orthogonal((cin, 1), gen, dtype)
+    return p
+
+
 def generator(style: Tensor, y: Tensor, p: Dict[str, Tensor], nl_style: Dict[str, Tensor],
               nl_up: Optional[Dict[str, Tensor]], attn_blocks: str = "B3",
               bn_stats: Optional[dict] = None, training: bool = True) -> Tensor:

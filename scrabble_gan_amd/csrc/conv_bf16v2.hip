@@ -40,6 +40,8 @@ struct SgIgemm2Args {
   const float* bias2;
   const float* mask;   // nullable, fp32, same shape as out: result := 0 where mask <= 0
   const u16* mask16;   // nullable alternative to `mask`: the same tensor as bf16 (sign and zero are what matter)
+  const float* amax_a; // fp8 operands only: device scalars max|activation| and max|filter| behind the per-tensor scales
+  const float* amax_w; //   (operand = fp8(value * 448 / amax)); the epilogue multiplies the sums by amax_a * amax_w / 448^2
   int Bn, Ha, Wa, Ca;
   int Hg, Wg, a_sy, a_sx;
   int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
@@ -94,14 +96,17 @@ constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A s
 
 // BN = 256: 2 x 4 waves, wave tile 128 x 64 (the large layers);  BN = 128: 4 x 2 waves, 64 x 64;  BN = 64: 8 x 1 waves,
 // 32 x 64 (the 64-filter layers, which are bandwidth-bound anyway).  The A tile is always 256 rows.
-template <int BN>
+// ES = bytes per operand element: 2 = bf16 (k-tile = 64 channels, four 32x32x16 MFMA steps), 1 = fp8 e4m3 (k-tile = 128
+// channels, two v_mfma_scale_f32_32x32x64_f8f6f4 steps with unit block scales: 2x the bf16 rate per clock).  The byte
+// geometry of the tiles (128-byte rows, 16-byte chunks, swizzle, DMA roles) is the same for both.
+template <int BN, int ES>
 __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int BM = SG2_BM, BK = SG2_BK;
+  constexpr int BM = SG2_BM, BK = 128 / ES;            // channels per k-tile
   constexpr int WN = BN / 64, WM = 8 / WN;              // waves along n / m
   constexpr int TM = BM / WM / 32, TN = 2;              // 32 x 32 MFMA tiles per wave
   constexpr int BQ = BN / 64;                           // B-tile DMA instructions per thread
-  constexpr int BTILE = BN * BK * 2;                    // bytes of the B tile
+  constexpr int BTILE = BN * 128;                       // bytes of the B tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,21 +150,21 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     const int yg = rem / p.Wg;
     const int xg = rem - yg * p.Wg;
     const int y = yg * p.a_sy, x = xg * p.a_sx;
-    a_off[i] = 2u * (unsigned)(((b * p.Ha + y) * p.Wa + x) * p.Ca) + 16u * chunk;
+    a_off[i] = (unsigned)ES * (unsigned)(((b * p.Ha + y) * p.Wa + x) * p.Ca) + 16u * chunk;
     unsigned mk = 0;
     for (int t = 0; t < p.ntaps; ++t) {
       const int iy = y + p.taps[t].dy, ix = x + p.taps[t].dx;
       if (ok && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) mk |= 1u << t;
     }
     a_msk[i] = mk;
-    b_off[i] = 2u * (unsigned)((n0 + (r % BN)) * p.Ca) + 16u * chunk;       // (instructions i >= BN / 64 are not issued)
+    b_off[i] = (unsigned)ES * (unsigned)((n0 + (r % BN)) * p.Ca) + 16u * chunk;       // (instructions i >= BN / 64 are not issued)
   }
   // tap constants live in the lanes of two VGPRs (lane t = tap t): {byte offset of the tap in the activation, byte offset
   // of the tap's slab in the packed filter}; v_readlane with the (uniform) tap cursor fetches them without a memory access
   int tab_a = 0, tab_w = 0;
   if (lane < p.ntaps) {
-    tab_a = 2 * (p.taps[lane].dy * p.Wa + p.taps[lane].dx) * p.Ca;
-    tab_w = 2 * p.taps[lane].w_off;
+    tab_a = ES * (p.taps[lane].dy * p.Wa + p.taps[lane].dx) * p.Ca;
+    tab_w = ES * p.taps[lane].w_off;
   }
   int lt = kt_begin % p.ntaps, lc0 = (kt_begin / p.ntaps) * BK;         // cursor of the tile being loaded
   int lidx = 0;                                                          // its index in this workgroup's reduction range
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   // serialises the fragment prefetch), and a phantom tile's products are zeros.
   auto set_cursor = [&]() {
     cur_live = lidx < KT;
-    cur_a = __builtin_amdgcn_readlane(tab_a, lt) + 2 * lc0;
-    cur_w = __builtin_amdgcn_readlane(tab_w, lt) + 2 * lc0;
+    cur_a = __builtin_amdgcn_readlane(tab_a, lt) + ES * lc0;
+    cur_w = __builtin_amdgcn_readlane(tab_w, lt) + ES * lc0;
     cur_bit = cur_live ? (1u << lt) : 0u;
   };
   set_cursor();
@@ -262,17 +267,6 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     __builtin_amdgcn_sched_barrier(0);                                          \
   } while (0)
 
-  {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) issue_part(0, q);
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_part(1, 0);
-    issue_part(1, 1);
-    SG2_READ_FRAGS(0, 0, 0);
-  }
-
   // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, parts 0-1 of tile t+1 issued.
   // After step 2: tile t+1 has landed (this wave's DMAs; the barrier extends that to every wave's) and every wave has its
   // last fragments of stage `st` in registers, so stage `st` is free for tile t+2.
@@ -302,9 +296,87 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     mma(1);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
+  // ---------------- fp8: two k-steps of 64 channels per tile; a fragment = 32 bytes = two swizzled 16-byte chunks
+  typedef int v8i __attribute__((ext_vector_type(8)));
+  unsigned a8[2][2], b8[2][2];                       // [step][chunk half] byte addresses of row `frow`
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned ko = 16u * (unsigned)((4 * s + 2 * khalf + e) ^ swz);
+      a8[s][e] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
+      b8[s][e] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+    }
+  // ONE fragment set (48 registers; a second one does not fit beside the 128 accumulators): the reads of the next step are
+  // issued right behind the MFMAs of the current one (an MFMA takes its operands at issue), the partner wave of the SIMD
+  // covers most of the read latency
+  v4i afl[1][4], afh[1][4], bfl[1][2], bfh[1][2];    // [slot][group], low / high 16 bytes of a fragment
+#define SG8_READ_FRAGS(st, s, slot)                                                          \
+  do {                                                                                       \
+    SG2_DSR(afl[slot][0], a8[s][0], (st) * SG2_TILE + 0 * 4096);                             \
+    SG2_DSR(afh[slot][0], a8[s][1], (st) * SG2_TILE + 0 * 4096);                             \
+    if constexpr (TM > 1) SG2_DSR(afl[slot][1], a8[s][0], (st) * SG2_TILE + 1 * 4096);       \
+    if constexpr (TM > 1) SG2_DSR(afh[slot][1], a8[s][1], (st) * SG2_TILE + 1 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afl[slot][2], a8[s][0], (st) * SG2_TILE + 2 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afh[slot][2], a8[s][1], (st) * SG2_TILE + 2 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afl[slot][3], a8[s][0], (st) * SG2_TILE + 3 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afh[slot][3], a8[s][1], (st) * SG2_TILE + 3 * 4096);       \
+    SG2_DSR(bfl[slot][0], b8[s][0], (st) * BTILE + 0 * 4096);                                \
+    SG2_DSR(bfh[slot][0], b8[s][1], (st) * BTILE + 0 * 4096);                                \
+    SG2_DSR(bfl[slot][1], b8[s][0], (st) * BTILE + 1 * 4096);                                \
+    SG2_DSR(bfh[slot][1], b8[s][1], (st) * BTILE + 1 * 4096);                                \
+  } while (0)
+  auto mma8 = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const v8i a = __builtin_shufflevector(afl[slot][i], afh[slot][i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const v8i b = __builtin_shufflevector(bfl[slot][j], bfh[slot][j], 0, 1, 2, 3, 4, 5, 6, 7);
+        // cbsz = blgp = 0: both operands fp8 e4m3; E8M0 scale 127 = 2^0 on both sides
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[i][j], 0, 0, 0, 127, 0, 127);
+      }
+    }
+  };
+#define SG8_WAIT_ALL() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SG8_K_TILE(st, sn)                                                             \
+  do {                                                                                 \
+    issue_part(sn, 2);                                                                 \
+    issue_part(sn, 3);                                                                 \
+    advance();                                                                         \
+    SG8_WAIT_ALL();                                                                    \
+    mma8(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    SG8_READ_FRAGS(st, 1, 0);                                                          \
+    SG8_WAIT_ALL();                                                                    \
+    mma8(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+    __builtin_amdgcn_s_barrier();                                                      \
+    issue_part(st, 0);                                                                 \
+    issue_part(st, 1);                                                                 \
+    SG8_READ_FRAGS(sn, 0, 0);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+  {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_part(0, q);
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_part(1, 0);
+    issue_part(1, 1);
+    if constexpr (ES == 2) SG2_READ_FRAGS(0, 0, 0);
+    else SG8_READ_FRAGS(0, 0, 0);
+  }
   for (int kt = 0; kt < KT; kt += 2) {          // two tiles per iteration: the stage index is a compile-time constant;
-    SG2_K_TILE(0, 1);                           // with KT odd the last tile of the last iteration is a phantom tile
-    SG2_K_TILE(1, 0);
+    if constexpr (ES == 2) {                    // with KT odd the last tile of the last iteration is a phantom tile
+      SG2_K_TILE(0, 1);
+      SG2_K_TILE(1, 0);
+    } else {
+      SG8_K_TILE(0, 1);
+      SG8_K_TILE(1, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the phantom tiles' DMAs and fragment reads
   __builtin_amdgcn_sched_barrier(0);
@@ -313,6 +385,8 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   const bool accum = (p.flags & SG_ACCUM) != 0;
   const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
   const bool ident = (p.flags & SG2_IDENT_OUT) != 0;
+  float oscale = 1.f;
+  if constexpr (ES == 1) oscale = p.amax_a[0] * p.amax_w[0] * (1.f / (448.f * 448.f));
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -336,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
           const int xg = rem - yg * p.Wg;
           idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
         }
-        float v = acc[i][j][r] + bsum;
+        float v = acc[i][j][r] * oscale + bsum;
         if (p.mask16) {
           const short mv = (short)p.mask16[idx];
           if (mv <= 0) v = 0.f;           // bf16 <= 0  <=>  its int16 is negative or +0 (-0 = 0x8000 is negative as int16)
@@ -359,13 +433,13 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
 static int g2_split_override = -1;
 extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
 
-template <int BN>
+template <int BN, int ES>
 static int sg2_launch_bn(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int n_tiles = a.N / BN;
   const int tiles = sg_cdiv(M, SG2_BM) * n_tiles;
   if (tiles <= 0) return SG_OK;
-  const int KT_all = a.ntaps * (a.Ca / SG2_BK);
+  const int KT_all = a.ntaps * (a.Ca / (128 / ES));
   // one workgroup per CU: a launch of T equal tiles takes ceil(T / 256) tile-times; the tiles beyond the last multiple of
   // 256 (all of them when T < 512) are cut along the reduction and summed with float atomics (model of launch_cfg in
   // conv_igemm.hip at OCC = 1)
@@ -399,33 +473,35 @@ static int sg2_launch_bn(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   a.tail_split = nsplit;
   a.n_tiles_total = tiles;
   static bool attr_done = false;
-  constexpr int LDS_BYTES = 2 * SG2_TILE + 2 * BN * SG2_BK * 2;
+  constexpr int LDS_BYTES = 2 * SG2_TILE + 2 * BN * 128;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(sg_igemm_bf16v2_kernel<BN>, dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((sg_igemm_bf16v2_kernel<BN, ES>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   return sg_launch_status();
 }
 
 // -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
 // rows of reduction-split tiles are summed by atomics: their bf16 copy needs a convert pass afterwards)
-static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done) {
+static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done, int es = 2) {
   SgIgemm2Args a = a_in;
-  if ((a.Ca % SG2_BK) || (a.N % 64) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
-  const long a_bytes = 2L * a.Bn * a.Ha * a.Wa * a.Ca;
+  if ((a.Ca % (128 / es)) || (a.N % 64) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
+  if (es == 1 && ((a.N % 256) || !a.amax_a || !a.amax_w)) return SG_ERR_UNSUPPORTED;
+  const long a_bytes = (long)es * a.Bn * a.Ha * a.Wa * a.Ca;
   long w_elems = 0;
   for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
   w_elems += (long)a.N * a.Ca;
-  if (a_bytes >= (1L << 32) - 64 || 2 * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
+  if (a_bytes >= (1L << 32) - 64 || es * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
-  if (a.N % 256 == 0) return sg2_launch_bn<256>(a, s, twin_rows_done);
-  if (a.N % 128 == 0) return sg2_launch_bn<128>(a, s, twin_rows_done);
-  return sg2_launch_bn<64>(a, s, twin_rows_done);
+  if (es == 1) return sg2_launch_bn<256, 1>(a, s, twin_rows_done);
+  if (a.N % 256 == 0) return sg2_launch_bn<256, 2>(a, s, twin_rows_done);
+  if (a.N % 128 == 0) return sg2_launch_bn<128, 2>(a, s, twin_rows_done);
+  return sg2_launch_bn<64, 2>(a, s, twin_rows_done);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -740,4 +816,134 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   }
   hipLaunchKernelGGL(sg_wgrad_bf16v2_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), SG2_LDS, (hipStream_t)stream, a);
   return sg_launch_status();
+}
+
+// ==========================================================================================================
+// fp8 (OCP e4m3) operands for the forward / data-grad convolutions of the D-shaped trunks (BASELINE config c5, first
+// slice): per-tensor scaling, fp32 accumulation.   operand8 = e4m3(clamp(value * 448 / amax, +-448)),  amax = max|tensor|
+// (device scalar: no host sync), result = sums * amax_a * amax_w / 448^2.  Weight gradients stay bf16 (gradient tensors
+// need per-tensor scales of their own AND e5m2 range; not in this slice).
+__global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long n4, unsigned* amax_bits) {
+  float m = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = sg_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));      // non-negative floats order like their bits
+}
+
+// amax[0] = max(amax[0], max_i |x_i|); the caller zeroes amax first.  n % 4 == 0.
+extern "C" int sg_amax_f32(const float* x, long n, float* amax, void* stream) {
+  if (!x || !amax || n < 0 || (n & 3)) return SG_ERR_ARG;
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(k_amax, dim3(sg_grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, reinterpret_cast<unsigned*>(amax));
+  return sg_launch_status();
+}
+
+__device__ __forceinline__ float sg8_scale(const float* amax) {
+  const float a = amax[0];
+  return a > 0.f ? 448.f / a : 1.f;
+}
+
+__device__ __forceinline__ unsigned sg8_pack4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -448.f), 448.f), fminf(fmaxf(b, -448.f), 448.f), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -448.f), 448.f), fminf(fmaxf(d, -448.f), 448.f), w, true);
+  return (unsigned)w;
+}
+
+__global__ __launch_bounds__(256) void k_cvt_fp8(const float* __restrict__ x, uint2* __restrict__ out, long n8, int relu, const float* amax) {
+  const float s = sg8_scale(amax);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+    float4 v0 = reinterpret_cast<const float4*>(x)[2 * e], v1 = reinterpret_cast<const float4*>(x)[2 * e + 1];
+    if (relu) {
+      v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+      v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+    }
+    out[e] = make_uint2(sg8_pack4(v0.x * s, v0.y * s, v0.z * s, v0.w * s), sg8_pack4(v1.x * s, v1.y * s, v1.z * s, v1.w * s));
+  }
+}
+
+// x fp32 [n] -> out fp8 e4m3 [n] = e4m3(relu?(x) * 448 / amax[0]); n % 8 == 0
+extern "C" int sg_cvt_fp8(const float* x, void* out, long n, int relu, const float* amax, void* stream) {
+  if (!x || !out || !amax || n < 0 || (n & 7)) return SG_ERR_ARG;
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(k_cvt_fp8, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out, n / 8, relu, amax);
+  return sg_launch_status();
+}
+
+// filter packing: fp32 [taps][K][N] (transpose = 1) or [taps][N][K] (transpose = 0) -> fp8 [taps][N][K], scaled by 448 / amax
+__global__ __launch_bounds__(256) void k_pack_filter_fp8(const float* w, unsigned char* out, const float* amax, int K, int N, int transpose) {
+  __shared__ float tile[32][33];
+  const float s = sg8_scale(amax);
+  const int t = blockIdx.z;
+  const float* wt = w + (size_t)t * K * N;
+  unsigned char* ot = out + (size_t)t * K * N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    if (transpose) {
+      const int k = k0 + r, n = n0 + tx;
+      tile[r][tx] = (k < K && n < N) ? wt[(size_t)k * N + n] : 0.f;       // tile[k][n]
+    } else {
+      const int n = n0 + r, k = k0 + tx;
+      tile[tx][r] = (k < K && n < N) ? wt[(size_t)n * K + k] : 0.f;       // tile[k][n]
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    if (n < N && k < K) ot[(size_t)n * K + k] = (unsigned char)(sg8_pack4(tile[tx][r] * s, 0.f, 0.f, 0.f) & 0xffu);
+  }
+}
+
+extern "C" int sg_pack_filter_fp8(const float* w, void* out, const float* amax, int taps, int K, int N, int transpose, void* stream) {
+  if (!w || !out || !amax || taps < 1 || K < 1 || N < 1) return SG_ERR_ARG;
+  hipLaunchKernelGGL(k_pack_filter_fp8, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+                     amax, K, N, transpose);
+  return sg_launch_status();
+}
+
+// Contracts of sg_conv2d_fwd_bf16v2 / sg_conv2d_bwd_data_bf16v2 with fp8 operands and their amax scalars.
+// SG_ERR_UNSUPPORTED unless reduction channels % 128 == 0 and output channels % 256 == 0 (caller: the bf16 entry points).
+extern "C" int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias,
+                                 const float* bias2, float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                 int pad_same, int flags, void* stream) {
+  if (!x8 || !wp8 || !amax_x || !amax_w || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (flags & SG_RELU_IN) return SG_ERR_UNSUPPORTED;           // fold the ReLU into sg_cvt_fp8
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)x8; a.w = (const u16*)wp8; a.out = y; a.out16 = (u16*)y16; a.bias = bias; a.bias2 = bias2;
+  a.amax_a = amax_x; a.amax_w = amax_w;
+  a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  long done = 0;
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 1);
+  return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
+}
+
+extern "C" int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, const void* wp8, const float* amax_w, const float* mask,
+                                      const void* mask16, float* dx, void* dx16, int B, int H, int W, int Cin, int Cout, int kh,
+                                      int kw, int pad_same, int flags, void* stream) {
+  if (!dy8 || !wp8 || !amax_dy || !amax_w || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)dy8; a.w = (const u16*)wp8; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask; a.mask16 = (const u16*)mask16;
+  a.amax_a = amax_dy; a.amax_w = amax_w;
+  a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
+  long done = 0;
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 1);
+  return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
 }

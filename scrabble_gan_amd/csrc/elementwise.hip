@@ -359,3 +359,45 @@ extern "C" int sg_dot_accum(const float* a, const float* b, float* out, long n, 
   hipLaunchKernelGGL(k_dot, dim3(sg_grid_for(n / 4, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
   return sg_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// host-pipeline helpers
+// ------------------------------------------------------------------------------------------
+// out[i] = (float(u8[i]) - 127.5) / 127.5   -- the pixel normalisation of load_prepare_data (data_utils.py:82) on the GPU,
+// same fp32 operations as the numpy expression (subtract, then divide), so the result is bit-identical
+__global__ __launch_bounds__(256) void k_normalize_u8(const uint4* __restrict__ in, float4* __restrict__ out, long n16) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n16; e += (long)gridDim.x * blockDim.x) {
+    const uint4 v = in[e];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 o;
+      o.x = ((float)(w[k] & 0xffu) - 127.5f) / 127.5f;
+      o.y = ((float)((w[k] >> 8) & 0xffu) - 127.5f) / 127.5f;
+      o.z = ((float)((w[k] >> 16) & 0xffu) - 127.5f) / 127.5f;
+      o.w = ((float)(w[k] >> 24) - 127.5f) / 127.5f;
+      out[4 * e + k] = o;
+    }
+  }
+}
+
+// u8 [n] (device) -> out fp32 [n]; n % 16 == 0
+extern "C" int sg_normalize_u8(const unsigned char* u8, float* out, long n, void* stream) {
+  if (!u8 || !out || n < 0 || (n & 15)) return SG_ERR_ARG;
+  if (n == 0) return SG_OK;
+  LAUNCH(k_normalize_u8, n / 16, stream, reinterpret_cast<const uint4*>(u8), reinterpret_cast<float4*>(out), n / 16);
+  return sg_launch_status();
+}
+
+// y[m, c] += bias[c]   (C % 4 == 0): the bias of a strided Conv2D expressed over the transposed-conv kernels
+__global__ __launch_bounds__(256) void k_bias_add(float* y, const float* bias, long n4, int c4) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x)
+    F4(y + 4 * e) = f4add(CF4(y + 4 * e), CF4(bias + 4 * (e % c4)));
+}
+
+extern "C" int sg_bias_add(float* y, const float* bias, long M, int C, void* stream) {
+  if (!y || !bias || M < 0 || C < 4 || (C & 3)) return SG_ERR_ARG;
+  if (M == 0) return SG_OK;
+  LAUNCH(k_bias_add, M * (C / 4), stream, y, bias, M * (C / 4), C / 4);
+  return sg_launch_status();
+}

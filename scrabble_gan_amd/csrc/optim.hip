@@ -131,6 +131,74 @@ extern "C" int sg_spectral_norm(const float* w, const float* u, float* out, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// spectral norm, backward (kernel_reg 'applied' mode: the forward convolves with w~ = w / sigma(w, u)).  One power iteration:
+//   a = W u,  v^ = a / |a|,  b = v^ W,  sigma = |b|,  u^ = b / |b|            (arch_ops.py:110-121; no stop-gradient)
+//   d sigma / dW = v^ u^T + g_a u^T... precisely  v^[k] u^[n] + g_a[k] u[n],   g_a = (t - (t . v^) v^) / |a|,  t = W u^
+//   dW += G / sigma - (<G, W> / sigma^2) * d sigma / dW                      (G = gradient w.r.t. w~)
+// ws = [a(K) | b(N) | t(K) | na2 | nb2 | nt_unused | s | c]   (floats)
+// ------------------------------------------------------------------------------------------
+// one wave per row: t[k] = sum_n W[k,n] b[n] rs_b ; c += t[k] a[k] rs_a ; s += sum_n G[k,n] W[k,n]
+__global__ __launch_bounds__(256) void k_snb_rows(const float* w, const float* g, const float* a, const float* b, const float* na2,
+                                                  const float* nb2, float* t, float* c, float* sdot, int K, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= K) return;
+  const float rs_b = rsqrtf(fmaxf(nb2[0], 1e-12f)), rs_a = rsqrtf(fmaxf(na2[0], 1e-12f));
+  float tt = 0.f, ss = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    const float wv = w[(size_t)row * N + n];
+    tt += wv * b[n];
+    ss += wv * g[(size_t)row * N + n];
+  }
+  tt = sg_wave_sum(tt) * rs_b;
+  ss = sg_wave_sum(ss);
+  if (lane == 0) {
+    t[row] = tt;
+    atomicAdd(c, tt * a[row] * rs_a);
+    atomicAdd(sdot, ss);
+  }
+}
+__global__ __launch_bounds__(256) void k_snb_apply(const float* g, const float* u, const float* a, const float* b, const float* t,
+                                                   const float* na2, const float* nb2, const float* c, const float* sdot, float* dw, int K, int N) {
+  const float nb = nb2[0], na = na2[0];
+  const float rs_b = rsqrtf(fmaxf(nb, 1e-12f)), rs_a = rsqrtf(fmaxf(na, 1e-12f));
+  const float sigma = nb * rs_b;                 // (v^ W) u^T = |b|^2 rsqrt(max(|b|^2, 1e-12))
+  const float inv = 1.f / sigma;
+  const float coef = sdot[0] * inv * inv;
+  const float cc = c[0];
+  const long total = (long)K * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / N), n = (int)(e - (long)k * N);
+    const float vh = a[k] * rs_a;
+    const float ga = (t[k] - cc * vh) * rs_a;
+    dw[e] += g[e] * inv - coef * (vh * b[n] * rs_b + ga * u[n]);
+  }
+}
+
+extern "C" long sg_spectral_norm_bwd_workspace_floats(int K, int N) { return 2L * K + N + 8; }
+
+// dw [K,N] += gradient w.r.t. w of  w~ = spectral_norm(w, u, power_iteration = 1)  given g = gradient w.r.t. w~
+extern "C" int sg_spectral_norm_bwd(const float* w, const float* u, const float* g, float* dw, float* workspace, int K, int N, void* stream) {
+  if (!w || !u || !g || !dw || !workspace || K < 1 || N < 1) return SG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* a = workspace;
+  float* b = workspace + K;
+  float* t = workspace + K + N;
+  float* na2 = workspace + 2L * K + N;
+  float* nb2 = na2 + 1;
+  float* sdot = na2 + 3;
+  float* c = na2 + 4;
+  (void)hipMemsetAsync(b, 0, sizeof(float) * N, s);
+  (void)hipMemsetAsync(na2, 0, sizeof(float) * 8, s);
+  hipLaunchKernelGGL(k_sn_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, u, (const float*)nullptr, a, na2, K, N);
+  hipLaunchKernelGGL(k_sn_cols, dim3(sg_cdiv(K, 64)), dim3(256), 0, s, w, a, na2, b, K, N, 64);
+  hipLaunchKernelGGL(k_sn_norm2, dim3(1), dim3(256), 0, s, b, nb2, N);
+  hipLaunchKernelGGL(k_snb_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, g, a, b, na2, nb2, t, c, sdot, K, N);
+  hipLaunchKernelGGL(k_snb_apply, dim3(sg_grid_for((long)K * N, 256)), dim3(256), 0, s, g, u, a, b, t, na2, nb2, c, sdot, dw, K, N);
+  return sg_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
 // loss head
 // ------------------------------------------------------------------------------------------
 // sums layout (fp64): 0 d_loss 1 d_real 2 d_fake 3 g_loss 4 s_loss 5 s_a 6 s_b 7 r_f 8 r_r 9 g^2 10 r_f^2 11 count

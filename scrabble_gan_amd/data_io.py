@@ -23,9 +23,10 @@ def _read_gray(path: str) -> np.ndarray:
         return np.asarray(im.convert("L"))
 
 
-def load_prepare_data(input_dim, batch_size, reading_dir, char_vector, bucket_size):
+def load_prepare_data(input_dim, batch_size, reading_dir, char_vector, bucket_size, raw=False):
     """Python generator of (images float32 [B,h,16L,c] in [-1,1], labels int32 [B,L]); one bucket per batch, the
-    bucket drawn with probability proportional to its population, samples drawn with replacement."""
+    bucket drawn with probability proportional to its population, samples drawn with replacement.
+    raw=True (not in the reference) yields the uint8 pixels [B,h,16L,c] instead: DevicePrefetcher normalises on the GPU."""
     data_buckets, bucket_weights, number_samples = {}, {}, 0
     for i in range(1, bucket_size + 1):
         imgs, labels = [], []
@@ -46,7 +47,11 @@ def load_prepare_data(input_dim, batch_size, reading_dir, char_vector, bucket_si
             k = random.randint(0, len(data_buckets[bucket][1]) - 1)
             image_batch.append(data_buckets[bucket][0][k])
             label_batch.append(data_buckets[bucket][1][k])
-        yield normalize_images(np.array(image_batch), input_dim, bucket), np.array(label_batch).astype(np.int32)
+        if raw:
+            h, _, c = input_dim
+            yield (np.array(image_batch, dtype=np.uint8).reshape(-1, h, int((h / 2) * bucket), c), np.array(label_batch).astype(np.int32))
+        else:
+            yield normalize_images(np.array(image_batch), input_dim, bucket), np.array(label_batch).astype(np.int32)
 
 
 def _fit_style_image(img: np.ndarray, h: int, w: int, validate: bool) -> np.ndarray:
@@ -81,3 +86,59 @@ def load_style_input(input_dim, batch_size, bucket_size, style_dir="../../scrabb
     train = [_fit_style_image(_read_gray(os.path.join(style_dir, f)), h, w, False) for f in files[:split]]
     validate = [_fit_style_image(_read_gray(os.path.join(style_dir, f)), h, w, True) for f in files[split:]]
     return train, validate
+
+
+class DevicePrefetcher:
+    """Host pipeline of SURVEY 8(f)-3 around a raw (uint8) batch generator: a background thread pulls the next batches and
+    stages their pixels in PINNED host buffers (torch's caching host allocator); next() queues an asynchronous
+    host-to-device copy of the bytes (a quarter of the fp32 volume) and the GPU-side pixel normalisation
+    (sg_normalize_u8 = data_utils.py:82) on the current stream and returns (images fp32 on the device, labels int32 numpy):
+    train_step takes device tensors as they are.  The generator itself runs on ONE thread in its own order, so the
+    `random` / `np.random` draw sequence of the reference loader is unchanged.  depth = batches staged ahead."""
+
+    def __init__(self, raw_batches, device, depth: int = 2):
+        import queue
+        import threading
+        import torch
+        self._torch = torch
+        self._device = torch.device(device)
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._stop = False
+
+        def work():
+            try:
+                for u8, labels in raw_batches:
+                    if self._stop:
+                        return
+                    u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+                    n = u8.size
+                    pad = (-n) % 16                                   # the kernel converts 16 pixels per thread
+                    buf = torch.empty(n + pad, dtype=torch.uint8, pin_memory=self._device.type == "cuda")
+                    buf[:n].copy_(torch.from_numpy(u8.reshape(-1)))
+                    if pad:
+                        buf[n:].zero_()
+                    self._q.put((buf, u8.shape, labels))
+                self._q.put(None)
+            except Exception as e:  # noqa: BLE001  (surface loader errors in the consumer)
+                self._q.put(e)
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        from . import ops
+        item = self._q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, Exception):
+            raise item
+        buf, shape, labels = item
+        n = int(np.prod(shape))
+        dev8 = buf.to(self._device, non_blocking=True)
+        return ops.normalize_u8(dev8)[:n].view(*shape), labels
+
+    def close(self):
+        self._stop = True

@@ -166,7 +166,8 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     x_f, ctx_g = G.forward(style, fake_t, nl.get("G.style"), nl.get("G.up"), training=True)
     B = x_f.shape[0]
     il_f, il_r = ctc_input_length(L_f), ctc_input_length(L_r)
-    fuse = fuse_passes and x_f.shape == images.shape
+    plain = all(getattr(m, "supports_fused_passes", True) for m in (D, S))     # (make_my_discriminator: separate passes and sweeps)
+    fuse = fuse_passes and plain and x_f.shape == images.shape
     if fuse:
         (d_f, d_r), ctx_D, _ = D.forward_multi([x_f, images], [nl.get("D.fake"), nl.get("D.real")])
         fuse_style = style.shape == x_f.shape
@@ -208,7 +209,7 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     # scalar, so ONE sweep with upstream u_b produces both: sample b enters the weight gradients with factor
     # gD_f[b]/u_b and the image gradient is rescaled by gG_d[b]/u_b (factors from the loss-head kernel, |.| <= 1).
     g_step = (batch_idx + 1) % disc_iters == 0
-    share = share_backward and g_step
+    share = share_backward and g_step and plain
     ones_b = torch.ones(B, device=dev)
     for m in (D, R, S):
         m.store.zero_grad()

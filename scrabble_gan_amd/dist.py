@@ -57,6 +57,58 @@ class DistReducer(Reducer):
         return t[self.rank * b:(self.rank + 1) * b].contiguous()
 
 
+class AbiReducer(DistReducer):
+    """The same exchanges with the gradient / statistics all-reduces issued through the C-ABI entry
+    (`sg_allreduce_sum` -> ncclAllReduce of librccl) instead of torch.distributed's wrapper.  torch.distributed is still
+    used once, to hand rank 0's RCCL unique id to the other ranks.  Selected with SG_COLLECTIVE=abi (one GPU per rank).
+    Collectives run on a side stream ordered after the kernels already queued on the launch stream (event), so an
+    asynchronous exchange overlaps the kernels queued after it, exactly like the torch.distributed path."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        import ctypes
+        from ._lib import call
+        self._call = call
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            call("sg_rccl_unique_id", ctypes.addressof(ident))
+        raw = self.broadcast_object(bytes(ident.raw)) if self.world_size > 1 else bytes(ident.raw)
+        comm = ctypes.c_void_p()
+        call("sg_rccl_comm_init_rank", ctypes.addressof(comm), self.world_size, raw, self.rank)
+        self._comm = comm.value
+        self._side = torch.cuda.Stream()
+
+    _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 3}
+
+    def _launch(self, t: torch.Tensor):
+        assert t.is_cuda and t.is_contiguous()
+        self.calls += 1
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self._side.wait_event(ready)
+        self._call("sg_allreduce_sum", t.data_ptr(), t.numel(), self._DT[t.dtype], self._comm, self._side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self._side)
+        return done
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        torch.cuda.current_stream().wait_event(self._launch(t))
+        return t
+
+    def all_reduce_sum_async(self, t: torch.Tensor):
+        return self._launch(t)
+
+    def wait(self, handle) -> None:
+        if handle is not None:
+            torch.cuda.current_stream().wait_event(handle)
+
+    def close(self):
+        if self._comm:
+            self._call("sg_rccl_comm_destroy", self._comm)
+            self._comm = None
+
+
 def init_from_env(backend: str = "nccl") -> "Reducer":
     """Build the reducer from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,4 +120,6 @@ def init_from_env(backend: str = "nccl") -> "Reducer":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
+    if os.environ.get("SG_COLLECTIVE", "torch") == "abi" and backend == "nccl":
+        return AbiReducer()
     return DistReducer()

@@ -17,8 +17,8 @@ import numpy as np
 from . import gin_config as gin
 from .arch_ops import spectral_norm
 from .data_utils import load_random_word_list, synthetic_batch, synthetic_random_words, train
-from .net_architecture import (configure, make_discriminator, make_gan, make_generator, make_my_recognizer, make_recognizer,
-                               make_style_promoter)
+from .net_architecture import (configure, make_discriminator, make_gan, make_generator, make_my_discriminator, make_my_recognizer,
+                               make_recognizer, make_style_promoter)
 from .net_loss import hinge, not_saturating
 from .optimizers import Adam, RMSprop
 
@@ -55,10 +55,11 @@ def setup_io(base_path, checkpoint_dir, gen_imgs_dir, model_dir, raw_dir, read_d
 def build_models(in_dim, latent_dim, embed_y, kernel_reg, g_bw_attention, d_bw_attention, n_classes, seq_len, my_rec=0, my_disc=0,
                  vis_model=False):
     """The factory call order of main.py:73-87."""
-    if my_disc:
-        raise NotImplementedError("make_my_discriminator is out of scope (its call site in the reference has the wrong arity)")
     generator = make_generator(latent_dim, in_dim, embed_y, kernel_reg, g_bw_attention, n_classes, vis_model=vis_model)
-    discriminator = make_discriminator(in_dim, kernel_reg, d_bw_attention, vis_model=vis_model)
+    if my_disc:      # (the reference's call site main.py:75 omits gen_path; the factory keeps the declared signature :417)
+        discriminator = make_my_discriminator("", in_dim, kernel_reg, vis_model=vis_model)
+    else:
+        discriminator = make_discriminator(in_dim, kernel_reg, d_bw_attention, vis_model=vis_model)
     rec_factory = make_my_recognizer if my_rec else make_recognizer
     recognizer = rec_factory(in_dim, seq_len, n_classes + 1, vis_model=vis_model)
     style_promoter = make_style_promoter(in_dim, kernel_reg, d_bw_attention, vis_model=vis_model)
@@ -115,9 +116,11 @@ def main(argv=None):
     else:
         if not os.path.exists(read_dir):
             raise FileNotFoundError("%s not found: the IAM conversion (dinterface) is out of scope; use --synthetic" % read_dir)
-        from .data_io import load_prepare_data, load_style_input      # "next" tier
+        from .data_io import DevicePrefetcher, load_prepare_data, load_style_input      # "next" tier
+        from .net_architecture import _device
         random_words = load_random_word_list(read_dir, bucket_size, char_vec)
-        train_dataset = load_prepare_data(in_dim, batch_size, read_dir, char_vec, bucket_size)
+        # uint8 pixels staged in pinned memory by a background thread, copied asynchronously, normalised on the GPU
+        train_dataset = DevicePrefetcher(load_prepare_data(in_dim, batch_size, read_dir, char_vec, bucket_size, raw=True), _device())
         train_imgs, _ = load_style_input(in_dim, batch_size, bucket_size)
 
     generator, discriminator, recognizer, style_promoter, gan = build_models(

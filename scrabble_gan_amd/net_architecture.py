@@ -47,10 +47,11 @@ def get_in_out_channels_disc(colors=1, resolution=32):
     return [colors] + out_channels[:-1], out_channels
 
 
-_DEFAULTS = {"device": None, "seed": 0, "nl_mode": "reference", "reducer": LOCAL}
+_DEFAULTS = {"device": None, "seed": 0, "nl_mode": "reference", "reducer": LOCAL, "kernel_reg_mode": "reference"}
 
 
-def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=None, deterministic=None):
+def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=None, deterministic=None, sync_bn=None,
+              kernel_reg_mode=None):
     """Process-wide construction defaults (device, init seed, NonLocalBlock mode, DP reducer) and the matrix-core
     operand type of the convolutions ('f32' = parity mode, 'bf16' = BASELINE config c3).
 
@@ -59,10 +60,17 @@ def configure(device=None, seed=None, nl_mode=None, reducer=None, conv_dtype=Non
     of the per-rank batch size (a few percent slower: the tail tiles of a launch no longer balance over the CUs).  The
     weight-gradient, bias-gradient and attention-dK/dV kernels still add partial sums with float atomics, so weights agree
     between runs to fp32 rounding, not bitwise.  Default runs are NOT bitwise reproducible (README)."""
-    if conv_dtype is not None:
+    if conv_dtype is not None:          # 'f32' | 'bf16' | 'fp8'
         ops.set_conv_dtype(conv_dtype)
     if deterministic is not None:
         ops.set_deterministic(bool(deterministic))
+    if kernel_reg_mode is not None:
+        # 'reference': kernel_reg is accepted and never applied, like the lazily evaluated Keras regularizer losses nobody
+        # reads (SURVEY fact 2) -- the parity mode.  'applied': every forward pass convolves with w / sigma (nn.AppliedSNStore).
+        assert kernel_reg_mode in ("reference", "applied")
+        _DEFAULTS["kernel_reg_mode"] = kernel_reg_mode
+    if sync_bn is not None:          # data parallel: global (True, default) or per-rank (False) BatchNorm statistics
+        (reducer if reducer is not None else _DEFAULTS["reducer"]).sync_bn = bool(sync_bn)
     if device is not None:
         _DEFAULTS["device"] = torch.device(device)
     if seed is not None:
@@ -100,6 +108,20 @@ class _Model:
         self.store = ParamStore(specs, self.device, gen)
         self.trainable = True
         self.reducer: Reducer = _DEFAULTS["reducer"]
+        self.kernel_reg_mode = _DEFAULTS["kernel_reg_mode"]
+        self.sn_gen = torch.Generator().manual_seed(gen.initial_seed() + 13)
+
+    def _pass_store(self):
+        """The parameter view of ONE forward pass (and its backward sweeps): the store itself, or, with kernel_reg applied,
+        spectrally normalised kernels with a fresh u (only when a kernel_reg callable was given to the factory)."""
+        if self.kernel_reg_mode == "applied" and getattr(self, "kernel_reg", None) is not None:
+            return nn.AppliedSNStore(self.store, nn.sn_names(self.store), self.sn_gen)
+        return self.store
+
+    @staticmethod
+    def _fold(S):
+        if isinstance(S, nn.AppliedSNStore):
+            S.fold()
 
     @property
     def trainable_variables(self) -> List[torch.Tensor]:
@@ -233,9 +255,10 @@ class DiscriminatorModel(_Model):
 
     def forward(self, x, nl=None):
         x = _as_nhwc1(x, self.device)
-        h, tctx = self.trunk.fwd(x, self.store, nl, self.nl_gen)
-        logits = ops.dense_fwd(h, self.store.p["dense.w"])                     # [B,1]
-        return logits, (tctx, h)
+        S = self._pass_store()
+        h, tctx = self.trunk.fwd(x, S, nl, self.nl_gen)
+        logits = ops.dense_fwd(h, S.p["dense.w"])                              # [B,1]
+        return logits, (tctx, h, S)
 
     def forward_multi(self, xs, nls):
         """Several reference calls of this model (same input width) as ONE pass over the concatenated batch: the
@@ -247,24 +270,28 @@ class DiscriminatorModel(_Model):
             bounds.append((lo, lo + x.shape[0]))
             lo += x.shape[0]
         segs = [(a, b, nl) for (a, b), nl in zip(bounds, nls)]
-        h, tctx = self.trunk.fwd(torch.cat(xs, 0), self.store, None, self.nl_gen, segments=segs)
-        logits = ops.dense_fwd(h, self.store.p["dense.w"])
-        return [logits[a:b] for a, b in bounds], (tctx, h), bounds
+        S = self._pass_store()
+        h, tctx = self.trunk.fwd(torch.cat(xs, 0), S, None, self.nl_gen, segments=segs)
+        logits = ops.dense_fwd(h, S.p["dense.w"])
+        return [logits[a:b] for a, b in bounds], (tctx, h, S), bounds
 
     def slice_ctx(self, ctx, lo, hi):
-        tctx, h = ctx
-        return self.trunk.slice_ctx(tctx, lo, hi), h[lo:hi]
+        tctx, h, S = ctx
+        return self.trunk.slice_ctx(tctx, lo, hi), h[lo:hi], S
 
     def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool, wscale=None):
         """`wscale` [B]: the data-gradient chain runs with upstream `dlogits`, while sample b contributes to the weight
         gradients with `wscale[b] * dlogits[b]` -- one sweep serving two targets (backprop is linear per sample)."""
-        tctx, h = ctx
+        tctx, h, S = ctx
         dlogits = dlogits.reshape(-1, self.units).contiguous()
         if want_dw:
             dl_w = dlogits if wscale is None else ops.rowscale(dlogits, wscale)
-            ops.dense_bwd_weight(h, dl_w, self.store.g["dense.w"])
-        dh = ops.dense_bwd_input(dlogits, self.store.p["dense.w"])
-        return self.trunk.bwd(tctx, dh, self.store, want_dx, want_dw, wscale=wscale)
+            ops.dense_bwd_weight(h, dl_w, S.g["dense.w"])
+        dh = ops.dense_bwd_input(dlogits, S.p["dense.w"])
+        dx = self.trunk.bwd(tctx, dh, S, want_dx, want_dw, wscale=wscale)
+        if want_dw:
+            self._fold(S)
+        return dx
 
     def __call__(self, inputs, training=False):
         x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
@@ -334,7 +361,8 @@ class GeneratorModel(_Model):
         return nl if nl is not None else nn.nonlocal_weights(C, self.nl_gen, self.device)
 
     def forward(self, style, y, nl_style=None, nl_up=None, training=True):
-        S, p = self.store, self.store.p
+        S = self._pass_store()
+        p = S.p
         style = _as_nhwc1(style, self.device)
         y = _as_labels(y, self.device)
         h, tctx = self.trunk.fwd(style, S, nl_style, self.nl_gen)                 # :241-250
@@ -356,12 +384,15 @@ class GeneratorModel(_Model):
         else:
             yb, bctx = ops.bn_apply(net, p["bn.mm"], p["bn.mv"], p["bn.gamma"], p["bn.beta"], False, True), None
         img = ops.conv2d_fwd(yb, p["final.w"], p["final.b"], tanh_out=True)        # :283-289
-        return img, (tctx, h, z, y, up_ctx, bctx, yb, img)
+        return img, (tctx, h, z, y, up_ctx, bctx, yb, img, S)
 
     def backward(self, ctx, dimg, on_tail_ready=None):
         """`on_tail_ready(offset)` (optional) is called once every gradient in `store.grad[offset:]` is final."""
-        S, p, g = self.store, self.store.p, self.store.g
-        tctx, h, z, y, up_ctx, bctx, yb, img = ctx
+        tctx, h, z, y, up_ctx, bctx, yb, img, S = ctx
+        p, g = S.p, S.g
+        applied = isinstance(S, nn.AppliedSNStore)
+        if applied:
+            on_tail_ready = None        # the shadow gradients are folded at the end: no early slice of the flat buffer is final
         d_pre = ops.tanh_bwd(img, dimg)
         ops.conv2d_bwd_weight(yb, d_pre, g["final.w"])
         ops.bias_grad(d_pre, g["final.b"])
@@ -383,6 +414,7 @@ class GeneratorModel(_Model):
             on_tail_ready(S._off["zdense.w"])
         dh = ops.dense_bwd_input(dz, p["zdense.w"])
         self.trunk.bwd(tctx, dh, S, want_dx=False, want_dw=True)
+        self._fold(S)
 
     def __call__(self, inputs, training=False):
         style, y = inputs[0], inputs[1]
@@ -448,6 +480,10 @@ class RecognizerModel(_Model):
 
     def forward(self, x, labels, input_length, label_length, training=True, need_grad=True):
         """-> per-sample CTC cost [B] (the model's OUTPUT is the loss, net_architecture.py:71-74), ctx."""
+        with ops.bf16_only():                  # config c5: the recognizer stays bf16 when G / D / S run fp8
+            return self._forward(x, labels, input_length, label_length, training, need_grad)
+
+    def _forward(self, x, labels, input_length, label_length, training=True, need_grad=True):
         p = self.store.p
         x = _as_nhwc1(x, self.device)
         labels = _as_labels(labels, self.device)
@@ -499,6 +535,10 @@ class RecognizerModel(_Model):
 
     def backward(self, ctx, upstream, want_dx: bool, want_dw: bool):
         """upstream [B] = d(target)/d(cost_b).  Returns d(target)/d(images) if want_dx."""
+        with ops.bf16_only():
+            return self._backward(ctx, upstream, want_dx, want_dw)
+
+    def _backward(self, ctx, upstream, want_dx: bool, want_dw: bool):
         p, g = self.store.p, self.store.g
         acts, feat, dlogits_unit, (B, T) = ctx
         dl = ops.rowscale(dlogits_unit, upstream.reshape(-1).contiguous()).view(B * T, self.classes)
@@ -713,6 +753,89 @@ class MyRecognizerModel(RecognizerModel):
             if masks is not None and k >= 3:
                 d = ops.mul_mask(d, masks["drop%d" % k])
         return d
+
+
+class MyDiscriminatorModel(_Model):
+    """make_my_discriminator (net_architecture.py:417-462): four Conv2D 3x3 stride (2,2) 'same' (16, 32, 64, 128 filters,
+    orthogonal, bias) each followed by LeakyReLU(0.3), a NonLocalBlock after the second, a second LeakyReLU after the
+    fourth, GlobalAveragePooling and Dense(1, no bias).  The NonLocalBlock runs on C = 32 (d_k = 4, d_v = 16): its freshly
+    drawn 1x1 kernels are zero-padded to the attention kernel's d_k = 8 / d_v = 32, which changes nothing
+    (zero key / query channels add 0 to every score, zero value channels meet zero rows of the output kernel)."""
+
+    FILTERS = (16, 32, 64, 128)
+    supports_fused_passes = False          # train_step runs every call of this model as its own pass, every tape its own sweep
+
+    def __init__(self, input_dim, kernel_reg):
+        h, w, c = input_dim
+        get_in_out_channels_disc(colors=c, resolution=h)          # the reference's argument checks (:421)
+        specs, cin = [], c
+        for i, co in enumerate(self.FILTERS):
+            specs += [("conv%d.w" % (i + 1), (3, 3, cin, co), nn.orthogonal, True), ("conv%d.b" % (i + 1), (co,), nn.zeros, True)]
+            cin = co
+        specs += [("NL_B1.sigma", (), nn.zeros, True), ("dense.w", (cin, 1), nn.orthogonal, True)]
+        gen = _gen_for("my_discriminator")
+        super().__init__("my_discriminator", specs, gen)
+        self.kernel_reg = kernel_reg
+        self.nl_gen = torch.Generator().manual_seed(gen.initial_seed() + 7)
+
+    @staticmethod
+    def pad_nl(nlw, device):
+        """The C = 32 NonLocalBlock kernels (theta / phi [32,4], g [32,16], o [16,32]) zero-padded to d_k 8 / d_v 32."""
+        t, ph, g, o = (nlw[k].reshape(nlw[k].shape[-2:]).to(device) for k in ("theta", "phi", "g", "o"))
+        C = t.shape[0]
+        tp, pp = torch.zeros(C, 8, device=device), torch.zeros(C, 8, device=device)
+        gp, op = torch.zeros(C, 32, device=device), torch.zeros(32, C, device=device)
+        tp[:, :t.shape[1]], pp[:, :ph.shape[1]], gp[:, :g.shape[1]], op[:o.shape[0]] = t, ph, g, o
+        return {"theta": tp, "phi": pp, "g": gp, "o": op}
+
+    def forward(self, x, nl=None):
+        p = self.store.p
+        x = _as_nhwc1(x, self.device)
+        if nl is None:
+            nl = nn.nonlocal_weights(32, self.nl_gen, torch.device("cpu"))
+        acts, net, nlc = [], x, None
+        for i in range(4):
+            pre = nn.strided_conv_fwd(net, p["conv%d.w" % (i + 1)], p["conv%d.b" % (i + 1)])
+            acts.append((net, pre))
+            net = ops.leaky_relu_fwd(pre, 0.3)
+            if i == 1:
+                net, nlc = nn.nonlocal_fwd(net, self.pad_nl(nl, self.device), p["NL_B1.sigma"])
+        last = ops.leaky_relu_fwd(net, 0.3)                         # the second LeakyReLU of :446
+        h = ops.gap_fwd(last, relu=False)
+        return ops.dense_fwd(h, p["dense.w"]), (acts, nlc, net, last, h)
+
+    def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool, wscale=None):
+        if wscale is not None:
+            raise NotImplementedError("shared backward sweeps are not wired for make_my_discriminator: pass share_backward=False")
+        p, g = self.store.p, self.store.g
+        acts, nlc, net4, last, h = ctx
+        dlogits = dlogits.reshape(-1, 1).contiguous()
+        if want_dw:
+            ops.dense_bwd_weight(h, dlogits, g["dense.w"])
+        d = ops.gap_bwd(ops.dense_bwd_input(dlogits, p["dense.w"]), last, relu=False)
+        d = ops.leaky_relu_bwd(d, net4, 0.3)
+        for i in reversed(range(4)):
+            xin, pre = acts[i]
+            if i == 1:
+                dsig = g["NL_B1.sigma"] if want_dw else torch.zeros(1, device=self.device)
+                d = nn.nonlocal_bwd(nlc, d, p["NL_B1.sigma"], dsig)
+            d = ops.leaky_relu_bwd(d, pre, 0.3)
+            gw = g["conv%d.w" % (i + 1)] if want_dw else torch.zeros_like(p["conv%d.w" % (i + 1)])
+            gb = g["conv%d.b" % (i + 1)] if want_dw else torch.zeros_like(p["conv%d.b" % (i + 1)])
+            d = nn.strided_conv_bwd(xin, p["conv%d.w" % (i + 1)], d, gw, gb, want_dx or i > 0)
+        return d
+
+    def __call__(self, inputs, training=False):
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        return self.forward(x)[0]
+
+
+def make_my_discriminator(gen_path, input_dim, kernel_reg, vis_model=True):
+    """The plain strided-conv discriminator alternative (net_architecture.py:417-462; `shared_specs.my_disc = 1`)."""
+    m = MyDiscriminatorModel(input_dim, kernel_reg)
+    if vis_model:
+        m.summary()
+    return m
 
 
 def make_my_recognizer(input_dim, sequence_length, output_classes, vis_model=True):

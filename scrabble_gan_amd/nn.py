@@ -107,10 +107,55 @@ class ParamStore:
         return sum(int(math.prod(self.shapes[n])) if self.shapes[n] else 1 for n in self.trainable_names())
 
 
+class AppliedSNStore:
+    """kernel_reg = 'applied' (the evident intent of scrabble_gan.gin:22 with arch_ops.py:98-126): one
+    forward pass of a network convolves with w~ = spectral_norm(w, u) for every weight the reference registers a
+    kernel_regularizer on (all Conv2D / Conv2DTranspose / Dense kernels of G, D and S; not biases, BatchNorm affines, the
+    filter bank or the recognizer), u ~ N(0,1) drawn afresh for the pass (arch_ops.py:110).  This object stands in for the
+    ParamStore during that pass and its backward sweeps: `p[name]` is w~ for those weights, `g[name]` a shadow gradient
+    (d/dw~); fold() pushes the shadow gradients through the power iteration (sg_spectral_norm_bwd) into the real store."""
+
+    def __init__(self, store: "ParamStore", names, gen: torch.Generator):
+        self.base = store
+        self.device = store.device
+        self._off = store._off
+        self.shapes = store.shapes
+        self.p = dict(store.p)
+        self.g = dict(store.g)
+        self.sn = {}
+        for n in names:
+            w = store.p[n]
+            u = torch.randn(w.shape[-1], generator=gen).to(store.device)        # [1, N] of arch_ops.py:110
+            self.p[n] = ops.spectral_norm(w, u).view(w.shape)
+            self.g[n] = torch.zeros_like(w)
+            self.sn[n] = u
+
+    def fold(self):
+        """real gradient += d w~/d w applied to the shadow gradient; the shadow gradients are then cleared."""
+        for n, u in self.sn.items():
+            ops.spectral_norm_bwd(self.base.p[n], u, self.g[n], self.base.g[n])
+            self.g[n].zero_()
+
+
+def sn_names(store: "ParamStore"):
+    """The weights that carry kernel_regularizer=k_reg in the reference: every trainable kernel with >= 2 dims except the
+    filter bank (arch_ops.py:85-87: add_weight without regularizer) -- resnet_ops.py:18,24,57,66,71,99,104,111;
+    net_architecture.py:254,286,345,404; arch_ops.py:40,46,57,65 (the NonLocalBlock kernels in 'persistent' mode)."""
+    return [n for n in store.trainable_names() if len(store.shapes[n]) >= 2 and n != "filter_bank"]
+
+
 class Reducer:
-    """Cross-rank sum hook (data parallel).  The default is the identity (one process)."""
+    """Cross-rank sum hook (data parallel).  The default is the identity (one process).
+
+    sync_bn: BatchNorm statistics of the generator are summed over all ranks (SyncBN: the step then equals the
+    single-device step on the global batch).  The 7 forward + 7 backward statistic exchanges of a step cannot
+    be merged into fewer collectives: each BatchNorm's input depends on the previous one's output, so the exchanges are
+    sequentially dependent (each is a <= 8 KB latency-bound all-reduce, ~14 x 20-30 us against a 55 ms step at the 8-way
+    shard size).  sync_bn=False (configure(sync_bn=False)) normalises with per-rank statistics instead: no BN collective
+    at all, not equivalent to the single-device step."""
 
     world_size = 1
+    sync_bn = True
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         return t
@@ -220,8 +265,9 @@ def nonlocal_fwd(x, nlw: Dict[str, torch.Tensor], sigma: torch.Tensor, out=None)
     phi, i_phi = ops.maxpool_fwd(ops.conv2d_fwd(x, w_p), 2, 2)             # :44-48
     gg, i_g = ops.maxpool_fwd(ops.conv2d_fwd(x, w_g), 2, 2)                # :55-59
     Nq, Nk = H * W, (H // 2) * (W // 2)
-    o, lse = ops.attention_fwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2))   # :51-52,61
-    oc = ops.conv2d_fwd(o.view(B, H, W, C // 2), w_o)                      # :62-65
+    dk, dv = w_t.shape[-1], w_g.shape[-1]     # C/8 and C/2 (zero-padded to the kernel's 8 / 32 for make_my_discriminator's C = 32)
+    o, lse = ops.attention_fwd(theta.view(B, Nq, dk), phi.view(B, Nk, dk), gg.view(B, Nk, dv))   # :51-52,61
+    oc = ops.conv2d_fwd(o.view(B, H, W, dv), w_o)                          # :62-65
     out = ops.scale_add(oc, x, sigma.view(1), out=out)                     # :67
     return out, (x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o))
 
@@ -231,19 +277,20 @@ def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Opt
     x, theta, phi, i_phi, gg, i_g, o, lse, oc, (w_t, w_p, w_g, w_o) = ctx
     B, H, W, C = x.shape
     Nq, Nk = H * W, (H // 2) * (W // 2)
+    dk, dv = w_t.shape[-1], w_g.shape[-1]
     ops.dot_accum(dout if wscale is None else ops.rowscale(dout, wscale), oc, dsigma.view(1))
     d_oc = ops.scale(dout, sigma.view(1))
     d_o = ops.conv2d_bwd_data(d_oc, w_o, (H, W))
-    dth, dph, dg = ops.attention_bwd(theta.view(B, Nq, C // 8), phi.view(B, Nk, C // 8), gg.view(B, Nk, C // 2),
-                                     o.view(B, Nq, C // 2), lse, d_o.view(B, Nq, C // 2))
-    dth = dth.view(B, H, W, C // 8)
-    dph_f = ops.maxpool_bwd(dph.view(B, H // 2, W // 2, C // 8), i_phi, 2, 2)
-    dg_f = ops.maxpool_bwd(dg.view(B, H // 2, W // 2, C // 2), i_g, 2, 2)
+    dth, dph, dg = ops.attention_bwd(theta.view(B, Nq, dk), phi.view(B, Nk, dk), gg.view(B, Nk, dv),
+                                     o.view(B, Nq, dv), lse, d_o.view(B, Nq, dv))
+    dth = dth.view(B, H, W, dk)
+    dph_f = ops.maxpool_bwd(dph.view(B, H // 2, W // 2, dk), i_phi, 2, 2)
+    dg_f = ops.maxpool_bwd(dg.view(B, H // 2, W // 2, dv), i_g, 2, 2)
     if dnlw is not None:     # 'persistent' mode: the 1x1 kernels are trainable
-        ops.conv2d_bwd_weight(o.view(B, H, W, C // 2), d_oc, dnlw["o"].view(1, 1, C // 2, C), sample_scale=wscale)
-        ops.conv2d_bwd_weight(x, dth, dnlw["theta"].view(1, 1, C, C // 8), sample_scale=wscale)
-        ops.conv2d_bwd_weight(x, dph_f, dnlw["phi"].view(1, 1, C, C // 8), sample_scale=wscale)
-        ops.conv2d_bwd_weight(x, dg_f, dnlw["g"].view(1, 1, C, C // 2), sample_scale=wscale)
+        ops.conv2d_bwd_weight(o.view(B, H, W, dv), d_oc, dnlw["o"].view(1, 1, dv, C), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dth, dnlw["theta"].view(1, 1, C, dk), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dph_f, dnlw["phi"].view(1, 1, C, dk), sample_scale=wscale)
+        ops.conv2d_bwd_weight(x, dg_f, dnlw["g"].view(1, 1, C, dv), sample_scale=wscale)
     dx = ops.conv2d_bwd_data(dth, w_t, (H, W))
     ops.conv2d_bwd_data(dph_f, w_p, (H, W), out=dx, accum=True)
     ops.conv2d_bwd_data(dg_f, w_g, (H, W), out=dx, accum=True)
@@ -255,8 +302,11 @@ def nonlocal_bwd(ctx, dout, sigma: torch.Tensor, dsigma: torch.Tensor, dnlw: Opt
 # --------------------------------------------------------------------------------------------
 def bn_train_fwd(x, gamma, beta, per_sample: bool, relu: bool, reducer: Reducer = LOCAL):
     B, H, W, C = x.shape
-    sums = reducer.all_reduce_sum(ops.bn_stats_sums(x))          # SyncBN: (sum x, sum x^2) over all ranks
-    count = B * H * W * reducer.world_size
+    sums = ops.bn_stats_sums(x)
+    sync = reducer.world_size > 1 and reducer.sync_bn
+    if sync:
+        sums = reducer.all_reduce_sum(sums)                      # SyncBN: (sum x, sum x^2) over all ranks
+    count = B * H * W * (reducer.world_size if sync else 1)
     mean, var = ops.bn_stats_finalize(sums, count, x)
     y = ops.bn_apply(x, mean, var, gamma, beta, per_sample, relu)
     return y, (x, y, mean, var, gamma, count)
@@ -266,7 +316,7 @@ def bn_train_bwd(ctx, dy, per_sample: bool, relu: bool, reducer: Reducer = LOCAL
     """-> dx, dgamma [B,C], dbeta [B,C] (per-sample sums), chan (fp64 [4C]); dgamma_c/dbeta_c [C] += per-channel grads."""
     x, y, mean, var, gamma, count = ctx
     dgamma, dbeta, chan = ops.bn_bwd_reduce(dy, y, x, mean, var, gamma, per_sample, relu, dgamma_c=dgamma_c, dbeta_c=dbeta_c)
-    if reducer.world_size > 1:
+    if reducer.world_size > 1 and reducer.sync_bn:
         C = x.shape[-1]
         red = reducer.all_reduce_sum(chan[:2 * C].clone())
         chan = torch.cat([red, chan[2 * C:]])
@@ -433,3 +483,34 @@ def bilstm_bwd(ctx, dout, S: ParamStore, pre: str, want_dw=True):
             dxm = ops.mul_mask(dxm, masks[di], rows_per_mask=T)
         dx = dxm if dx is None else ops.add(dx, dxm, out=dx)
     return dx
+
+
+# --------------------------------------------------------------------------------------------
+# Conv2D(3x3, strides (2,2), padding 'same') of make_my_discriminator (net_architecture.py:425-443), on the transposed-conv
+# kernels: a strided convolution IS the adjoint of Conv2DTranspose(padding='same') (even input,
+# pad_before 0, pad_after 1), so   forward = convT data-grad,  data-grad = convT forward,  weight-grad = convT weight-grad
+# with the operands swapped -- all with the SAME [kh,kw,Cin,Cout] kernel, no layout change.
+# --------------------------------------------------------------------------------------------
+def strided_conv_fwd(x, w, b):
+    kh, kw, Cin, Cout = w.shape
+    if Cin == 1:
+        # one input channel: the thin stride-1 kernel on every position, then the odd positions (stride-2 SAME on an even
+        # extent samples x[2i + k], stride-1 SAME x[y + k - 1]: out2[i, j] = out1[2i + 1, 2j + 1]); 4x the work of a layer
+        # that has 0.03 % of the network's FLOPs
+        full = ops.conv2d_fwd(x, w, b)
+        return full[:, 1::2, 1::2, :].contiguous()
+    y = ops.conv2d_transpose_bwd_data(x, w, stride=(2, 2))
+    return ops.bias_add(y, b)
+
+
+def strided_conv_bwd(x, w, dy, dw, db, want_dx: bool):
+    kh, kw, Cin, Cout = w.shape
+    ops.bias_grad(dy, db)
+    if Cin == 1:
+        B, H, W, _ = x.shape
+        dfull = torch.zeros(B, H, W, Cout, device=x.device)
+        dfull[:, 1::2, 1::2, :] = dy                          # scatter back to the odd positions (data movement only)
+        ops.conv2d_bwd_weight(x, dfull, dw)
+        return ops.conv2d_bwd_data(dfull, w, (H, W)) if want_dx else None
+    ops.conv2d_transpose_bwd_weight(dy, x, dw, stride=(2, 2))
+    return ops.conv2d_transpose_fwd(dy, w, stride=(2, 2)) if want_dx else None

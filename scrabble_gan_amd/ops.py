@@ -147,11 +147,70 @@ _PACK_CACHE = {}
 
 
 def set_conv_dtype(dtype: str) -> None:
+    """'f32' (parity mode), 'bf16' (config c3) or 'fp8' (config c5, first slice: fp8 e4m3 operands for the forward and
+    data-grad launches of the >= 128-channel 3x3 / 1x1 convolutions outside the recognizer, bf16 everywhere else)."""
     global CONV_DTYPE
-    if dtype not in ("f32", "bf16"):
-        raise ValueError("conv dtype must be 'f32' or 'bf16'")
+    if dtype not in ("f32", "bf16", "fp8"):
+        raise ValueError("conv dtype must be 'f32', 'bf16' or 'fp8'")
     CONV_DTYPE = dtype
     _PACK_CACHE.clear()
+    _TWINS.clear()
+
+
+_FP8_BLOCK = [0]
+
+
+class bf16_only:
+    """Context: no fp8 launches inside (the recognizer of config c5 stays bf16)."""
+
+    def __enter__(self):
+        _FP8_BLOCK[0] += 1
+
+    def __exit__(self, *exc):
+        _FP8_BLOCK[0] -= 1
+        return False
+
+
+def _low() -> bool:
+    return CONV_DTYPE in ("bf16", "fp8")
+
+
+def _fp8_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
+    return USE_V2 and CONV_DTYPE == "fp8" and not _FP8_BLOCK[0] and K % 128 == 0 and N % 256 == 0 and (same or (kh == 1 and kw == 1))
+
+
+def fp8_of(t: torch.Tensor, relu: bool = False):
+    """-> (fp8 e4m3 copy of relu?(t) * 448 / amax as a uint8 tensor, amax device scalar); one conversion per (t, relu)."""
+    key = (t.untyped_storage().data_ptr(), "fp8", bool(relu), t.storage_offset(), t.numel())
+    e = _TWINS.get(key)
+    if e is None:
+        _chk(t)
+        amax = torch.zeros(1, device=t.device)
+        out = torch.empty(t.shape, device=t.device, dtype=torch.uint8)
+        with _hbm("cvt_fp8", t, t, out):
+            call("sg_amax_f32", _p(t), t.numel(), _p(amax), _stream())
+            call("sg_cvt_fp8", _p(t), out.data_ptr(), t.numel(), int(relu), _p(amax), _stream())
+        e = (t, out, amax)
+        _TWINS[key] = e
+    return e[1], e[2]
+
+
+def packed_filter_fp8(w: torch.Tensor, kind: str):
+    """-> (fp8 copy [tap][N][K] of a Conv2D filter scaled by 448 / amax, amax device scalar); made once per optimizer step."""
+    key = (w.data_ptr(), tuple(w.shape), kind + "8", w._version)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[1], hit[2]
+    kh, kw, Cin, Cout = w.shape
+    amax = torch.zeros(1, device=w.device)
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.uint8)
+    call("sg_amax_f32", _p(w), w.numel(), _p(amax), _stream())
+    if kind == "fwd":
+        call("sg_pack_filter_fp8", _p(w), out.data_ptr(), _p(amax), kh * kw, Cin, Cout, 1, _stream())
+    else:
+        call("sg_pack_filter_fp8", _p(w), out.data_ptr(), _p(amax), kh * kw, Cout, Cin, 0, _stream())
+    _PACK_CACHE[key] = (w, out, amax)
+    return out, amax
 
 
 def set_deterministic(on: bool) -> None:
@@ -196,7 +255,7 @@ def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
 
 
 def _bf16_ok(K: int, N: int) -> bool:
-    return CONV_DTYPE == "bf16" and K % 8 == 0 and N > 32 and K > 1
+    return _low() and K % 8 == 0 and N > 32 and K > 1
 
 
 # ---- bf16 twins (second-generation bf16 path, conv_bf16v2.hip) ---------------------------------------------------
@@ -268,7 +327,7 @@ def bf16_of(t: torch.Tensor) -> torch.Tensor:
 
 
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
-    return USE_V2 and CONV_DTYPE == "bf16" and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
+    return USE_V2 and _low() and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
 
 
 def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,
@@ -284,7 +343,15 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
         out = empty(B, Ho, Wo, Cout, like=x)
     with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
-        if _v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+        if _fp8_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+            x8, ax = fp8_of(x, relu_in)                       # the operand ReLU is folded into the conversion
+            w8, aw = packed_filter_fp8(w, "fwd")
+            y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            call("sg_conv2d_fwd_fp8", x8.data_ptr(), _p(ax), w8.data_ptr(), _p(aw), _p(bias), _p(bias2), _p(out),
+                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(False, accum, relu_out), _stream())
+            if y16 is not None:
+                _twin_put(out, y16)
+        elif _v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
             x16 = bf16_of(x)
             y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
             call("sg_conv2d_fwd_bf16v2", x16.data_ptr(), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out),
@@ -311,7 +378,17 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
         out = empty(B, H, W, Cin, like=dy)
     with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
-        if _v2_ok(Cout, Cin, kh, kw, same):
+        if _fp8_ok(Cout, Cin, kh, kw, same):
+            dy8, ady = fp8_of(dy)
+            w8, aw = packed_filter_fp8(w, "bwd")
+            dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            m16 = None if mask is None else _twin_get(mask)
+            call("sg_conv2d_bwd_data_fp8", dy8.data_ptr(), _p(ady), w8.data_ptr(), _p(aw), None if m16 is not None else _p(mask),
+                 None if m16 is None else m16.data_ptr(), _p(out), None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout,
+                 kh, kw, int(same), _flags(accum=accum), _stream())
+            if dx16 is not None:
+                _twin_put(out, dx16)
+        elif _v2_ok(Cout, Cin, kh, kw, same):
             dy16 = bf16_of(dy)
             dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
             m16 = None if mask is None else _twin_get(mask)          # the ReLU mask as bf16 when a twin exists (half the bytes)
@@ -340,7 +417,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
-    if USE_V2 and CONV_DTYPE == "bf16" and Cin % 256 == 0 and Cout % 256 == 0 and (same or kh * kw == 1):
+    if USE_V2 and _low() and Cin % 256 == 0 and Cout % 256 == 0 and (same or kh * kw == 1):
         # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy; the bias
         # gradient (fp32 sums of the scaled dy) is its own memory-bound sweep
         x16 = bf16_of(x)
@@ -354,7 +431,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
-             _flags(relu_in) | (MMA_BF16 if CONV_DTYPE == "bf16" else 0), _stream())
+             _flags(relu_in) | (MMA_BF16 if _low() else 0), _stream())
 
 
 def conv2d_transpose_fwd(x, w, bias=None, bias2=None, stride=(2, 2), out=None, accum=False):
@@ -441,6 +518,25 @@ def add(a, b, out=None):
     with _hbm("elementwise", a, b, out):
         call("sg_add", _p(a), _p(b), _p(out), a.numel(), _stream())
     return out
+
+
+def normalize_u8(u8: torch.Tensor) -> torch.Tensor:
+    """uint8 pixels on the device -> fp32 (x - 127.5) / 127.5 (data_utils.py:82), same shape."""
+    assert u8.is_cuda and u8.dtype == torch.uint8 and u8.is_contiguous() and u8.numel() % 16 == 0
+    out = torch.empty(u8.shape, device=u8.device, dtype=torch.float32)
+    with _hbm("elementwise", u8, out):
+        call("sg_normalize_u8", u8.data_ptr(), _p(out), u8.numel(), _stream())
+    return out
+
+
+def bias_add(y, bias):
+    """y[..., c] += bias[c] in place."""
+    _chk(y, bias)
+    _touch(y)
+    C = y.shape[-1]
+    with _hbm("elementwise", y, y):
+        call("sg_bias_add", _p(y), _p(bias), y.numel() // C, C, _stream())
+    return y
 
 
 def relu_mask(dy, ref, out=None):
@@ -725,6 +821,15 @@ def spectral_norm(w, u, power_iteration=1):
     ws = empty(lib().sg_spectral_norm_workspace_floats(K, N), like=w)
     call("sg_spectral_norm", _p(w), _p(u), _p(out), _p(ws), K, N, int(power_iteration), _stream())
     return out
+
+
+def spectral_norm_bwd(w, u, g, dw):
+    """dw += gradient w.r.t. w of spectral_norm(w, u, 1) given g = gradient w.r.t. the normalised weight."""
+    _chk(w, u, g, dw)
+    N = w.shape[-1]
+    K = w.numel() // N
+    ws = empty(lib().sg_spectral_norm_bwd_workspace_floats(K, N), like=w)
+    call("sg_spectral_norm_bwd", _p(w), _p(u), _p(g), _p(dw), _p(ws), K, N, _stream())
 
 
 def loss_terms(d_r, d_f, s_my, s_f, s_r, mode: int):

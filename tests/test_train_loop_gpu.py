@@ -226,3 +226,33 @@ def test_full_state_save_and_resume(dev, tmp_path):
             # (the last gradient and its running square: run-to-run noise of the float atomics, amplified where a ReLU /
             #  max-pool decision sits on the edge -- the same 1e-3-of-max bar as the data-parallel comparison)
             assert (sa - sc).abs().max().item() <= 5e-3 * sa.abs().max().item() + 1e-12, (ma.name, k, (sa - sc).abs().max().item(), sa.abs().max().item())
+
+
+def test_device_prefetcher_matches_the_host_loader(dev, tmp_path):
+    """bucket folders -> background thread -> pinned staging -> async H2D of the uint8 pixels -> GPU-side
+    (x - 127.5) / 127.5.  Same seeds, same draw order: every batch is BIT-identical to what the reference-style host loader
+    (load_prepare_data, data_utils.py:14-84) produces, and train_step accepts the device tensors."""
+    import random
+    from PIL import Image
+    from scrabble_gan_amd import data_io
+    cv = 'abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ'
+    rng = np.random.default_rng(0)
+    for L, words in ((1, ["a", "Z", "q"]), (2, ["to", "Hi", "ab"]), (3, ["the", "Cat"])):
+        d = tmp_path / str(L)
+        d.mkdir()
+        for i, wd in enumerate(words):
+            Image.fromarray(rng.integers(0, 256, (32, 16 * L), dtype=np.uint8), mode="L").save(d / ("w%d.png" % i))
+            (d / ("w%d.txt" % i)).write_text(wd)
+    random.seed(3)
+    np.random.seed(3)
+    host = data_io.load_prepare_data((32, 160, 1), 5, str(tmp_path) + "/", cv, 3)
+    want = [next(host) for _ in range(6)]
+    random.seed(3)
+    np.random.seed(3)
+    pre = data_io.DevicePrefetcher(data_io.load_prepare_data((32, 160, 1), 5, str(tmp_path) + "/", cv, 3, raw=True), dev, depth=2)
+    for (im_h, lab_h), _ in zip(want, range(6)):
+        im_d, lab_d = next(pre)
+        assert im_d.is_cuda and im_d.dtype == torch.float32 and tuple(im_d.shape) == im_h.shape
+        assert np.array_equal(lab_d, lab_h)
+        assert np.array_equal(im_d.cpu().numpy(), im_h), "GPU-side normalisation must be bit-identical to the numpy expression"
+    pre.close()

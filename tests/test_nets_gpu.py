@@ -264,6 +264,22 @@ def _oracle_sn(P, names, seed):
     return out
 
 
+def _rescale_kernels(model, P, gen):
+    """Orthogonal initial kernels have sigma = 1 exactly (normalising them is the identity): give every regularised
+    kernel its own scale and a rank-one bump so that sigma, v^ and u^ all matter."""
+    from scrabble_gan_amd import nn
+    upd = {}
+    for n in nn.sn_names(model.store):
+        w = P[n]
+        K, N = w.numel() // w.shape[-1], w.shape[-1]
+        bump = torch.randn(K, 1, generator=gen, dtype=torch.float64) @ torch.randn(1, N, generator=gen, dtype=torch.float64)
+        s = 0.5 + 1.5 * torch.rand(1, generator=gen, dtype=torch.float64).item()
+        P[n] = (s * (w.reshape(K, N) + 0.3 * bump / math.sqrt(K))).reshape(w.shape)
+        upd[n] = P[n].float()
+    model.store.load(upd)
+    return P
+
+
 @pytest.mark.parametrize("which", ["discriminator", "generator"])
 def test_kernel_reg_applied(dev, which):
     """kernel_reg = 'applied' (SURVEY Appendix C-3): every regularised kernel is divided by its one-step power-iteration
@@ -277,7 +293,7 @@ def test_kernel_reg_applied(dev, which):
         gen = torch.Generator().manual_seed(31)
         if which == "discriminator":
             M = NA.make_discriminator((32, 160, 1), spectral_norm, "B1", vis_model=False)
-            P = perturb(M, gen)
+            P = _rescale_kernels(M, perturb(M, gen), gen)
             B, W = 3, 48
             x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
             nlo, nlg = nl_pair(64, gen, dev)
@@ -299,7 +315,7 @@ def test_kernel_reg_applied(dev, which):
                 close(M.store.g[k], v.grad, 2e-3, "grad " + k, at)
         else:
             M = NA.make_generator(128, (32, 160, 1), (32, 8192), spectral_norm, "B3", 52, vis_model=False)
-            P = perturb(M, gen)
+            P = _rescale_kernels(M, perturb(M, gen), gen)
             B, L = 2, 2
             style = torch.rand(B, 32, 32, 1, generator=gen, dtype=torch.float64) * 2 - 1
             y = torch.randint(0, 52, (B, L), generator=gen)

@@ -791,16 +791,21 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   a.c_tiles = Cin / 256;
   a.n_tiles = Cout / 256;
   const int combos = a.ntaps * a.c_tiles * a.n_tiles;
-  // ~8 workgroups per CU in whole rounds of the 256 CUs (one workgroup per CU at a time), at least 8 k-tiles each
-  const long max_chunks = (M + 511) / 512;
+  // Pixel chunks per combo.  One workgroup per CU at a time, so a launch of W workgroups takes ceil(W / 256) rounds of
+  // (k-tiles per chunk) x t_tile + t_epi, where t_epi is the 256 KB of float atomics every workgroup ends with (measured:
+  // WRITE_SIZE 550 MB per launch at 2304 workgroups, the chip adds ~1.3 TB/s -> ~50 us per round against ~0.9 us per
+  // k-tile).  Few long workgroups win: the count that minimises the modelled time, at least 4 k-tiles each.
+  static const int wg_env = getenv("SG_WGRAD2_CHUNKS") ? atoi(getenv("SG_WGRAD2_CHUNKS")) : 0;
+  const long tiles_all = (M + 63) / 64;
+  const long max_chunks = tiles_all / 4 > 0 ? tiles_all / 4 : 1;
   long nchunks = 1;
   double best = 1e30;
-  for (long c = (1024 + combos - 1) / combos; c <= (3072 + combos - 1) / combos; ++c) {
-    const long cc = c < 1 ? 1 : (c > max_chunks ? max_chunks : c);
+  for (long cc = 1; cc <= max_chunks && cc * combos <= 4096; ++cc) {
     const long Wg = combos * cc;
-    const double loss = (double)((Wg + 255) / 256) * 256.0 / (double)Wg * (1.0 + 0.004 * cc);
-    if (loss < best) { best = loss; nchunks = cc; }
+    const double t = (double)((Wg + 255) / 256) * ((double)((tiles_all + cc - 1) / cc) * 0.9 + 50.0);
+    if (t < best) { best = t; nchunks = cc; }
   }
+  if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + 63) / 64 * 64;
   nchunks = (M + mchunk - 1) / mchunk;

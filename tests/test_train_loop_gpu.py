@@ -123,9 +123,9 @@ def test_schedules_agree_at_headline_tile_geometry(dev):
     passes carry 64 / 96 samples -> 2 560+ output tiles per large conv launch: full rounds, the XCD remap AND the
     reduction-split tail are all active, nothing is forced through sg_debug_set_splitk).  Default schedule (fused passes,
     shared sweeps) vs fuse_passes=False / share_backward=False, hinge, no balancing, well-conditioned logits (D/S Dense
-    scaled as in tests/step_fixture.py).  fp32 summation order is all that differs: scalars 1e-5, gradients of D / R / S
-    5e-4 and of G 2e-3 of the network's largest gradient (sums over 3.3 M pixels in different orders; measured values in
-    gpurun_out/schedule_equivalence_bs32.txt)."""
+    scaled as in tests/step_fixture.py).  fp32 summation order is all that differs: scalars 1e-5, gradients 3e-4 of the
+    network's largest gradient (sums over 3.3 M pixels in different orders; measured on MI355X: <= 1.3e-4 for D / S, 3e-5 for
+    G and R, profiles/r02_schedule_equivalence_bs32.txt)."""
     import numpy as np
     from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, nn, optimizers
     B, L = 32, 10
@@ -166,7 +166,7 @@ def test_schedules_agree_at_headline_tile_geometry(dev):
             scale = gb[n].abs().max().item()
             err = (ga[n] - gb[n]).abs().max().item()
             lines.append("%s %s rel %.3e" % (other, n, err / scale))
-            if not err <= (2e-3 if n == "G" else 5e-4) * scale:
+            if not err <= 3e-4 * scale:
                 bad.append("%s: %s gradients differ by %.3e of %.3e" % (other, n, err, scale))
     try:
         os.makedirs("gpurun_out", exist_ok=True)

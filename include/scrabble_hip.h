@@ -80,8 +80,8 @@ int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float*
                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 /* dw [kh,kw,Cin,Cout] (fp32) += weight gradient of the SAME stride-1 convolution from bf16 operands x16 [B,H,W,Cin] and
  * dy16 [B,H,W,Cout] (tape of d_loss / s_loss / g_final, data_utils.py:449-468; per-sample factors already folded into dy16 by
- * sg_cvt_bf16).  flags: SG_RELU_IN on x16.  No bias gradient (sg_bias_grad).  SG_ERR_UNSUPPORTED unless Cin % 256 == 0 and
- * Cout % 256 == 0: the caller then uses sg_conv2d_bwd_weight. */
+ * sg_cvt_bf16).  flags: SG_RELU_IN on x16.  No bias gradient (sg_bias_grad).  SG_ERR_UNSUPPORTED unless (Cin % 64 == 0 and
+ * Cout % 256 == 0) or Cin == Cout == 64: the caller then uses sg_conv2d_bwd_weight. */
 int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
                                 int kh, int kw, int pad_same, int flags, void* stream);
 

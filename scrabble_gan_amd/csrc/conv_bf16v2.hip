@@ -381,50 +381,120 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the phantom tiles' DMAs and fragment reads
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue (fp32): accumulator row = pixel, lane = channel
+  // ---- epilogue, staged through LDS (free now) so that every global access is 16 bytes per lane.
+  // The accumulator layout (row = pixel in the registers, lane = channel) would give 4-byte stores and 4-byte mask loads
+  // in 128-byte half-wave segments: 64 store + 64 twin-store + 64 mask-load instructions per 32x64 sub-tile, and the
+  // 64-filter layers / the data-grads were epilogue-bound (round-2 probe: the bf16 copy alone cost 16 %, the mask 26 %).
+  // Each wave owns 8 KB of LDS: it writes one 32-row x 64-column fp32 sub-tile (32 ds_write_b32), reads it back as rows
+  // (8 ds_read_b128: lane -> row 4 it + (l >> 4), columns 4 (l & 15) .. + 3, conflict-free for ds_read_b128's lane
+  // groups), and applies scale / bias / mask / accumulate / ReLU on float4s: 8 x 16-byte stores (+ 8 x 8-byte twin stores).
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the operand stages
   const bool accum = (p.flags & SG_ACCUM) != 0;
   const bool relu_out = (p.flags & SG_RELU_OUT) != 0;
   const bool ident = (p.flags & SG2_IDENT_OUT) != 0;
   float oscale = 1.f;
   if constexpr (ES == 1) oscale = p.amax_a[0] * p.amax_w[0] * (1.f / (448.f * 448.f));
+  float* stage = reinterpret_cast<float*>(smem + wave * 8192);
+  const int c4 = lane & 15, rsub = lane >> 4;
+  const int ncol = n0 + wn * 64 + 4 * c4;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (split == 0) {
+    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + ncol); bsum.x += t.x; bsum.y += t.y; bsum.z += t.z; bsum.w += t.w; }
+    if (p.bias2) { const float4 t = *reinterpret_cast<const float4*>(p.bias2 + ncol); bsum.x += t.x; bsum.y += t.y; bsum.z += t.z; bsum.w += t.w; }
+  }
+  if (nsplit > 1) {
+    // reduction-split tile: partial sums meet through float atomics, straight from the accumulator layout (one 128-byte row
+    // segment per half-wave: the full atomic rate; the row-major float4 layout below would scatter every wave instruction
+    // over 4 rows x 16 separate dwords -- measured 340 vs 630 TF/s on the 4x20 layer)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    float bsum = 0.f;
-    if (p.bias && split == 0) bsum += p.bias[n];
-    if (p.bias2 && split == 0) bsum += p.bias2[n];
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      float bs = 0.f;
+      if (p.bias && split == 0) bs += p.bias[n];
+      if (p.bias2 && split == 0) bs += p.bias2[n];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const int m = m0 + row;
-        if (m >= M) continue;
-        size_t idx;
-        if (ident) {
-          idx = (size_t)m * p.N + n;
-        } else {
-          const int b = m / HW;
-          const int rem = m - b * HW;
-          const int yg = rem / p.Wg;
-          const int xg = rem - yg * p.Wg;
-          idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
-        }
-        float v = acc[i][j][r] * oscale + bsum;
-        if (p.mask16) {
-          const short mv = (short)p.mask16[idx];
-          if (mv <= 0) v = 0.f;           // bf16 <= 0  <=>  its int16 is negative or +0 (-0 = 0x8000 is negative as int16)
-        } else if (p.mask && p.mask[idx] <= 0.f) {
-          v = 0.f;
-        }
-        if (nsplit > 1) {
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (m >= M) continue;
+          size_t idx;
+          if (ident) {
+            idx = (size_t)m * p.N + n;
+          } else {
+            const int b = m / HW;
+            const int rem = m - b * HW;
+            const int yg = rem / p.Wg;
+            const int xg = rem - yg * p.Wg;
+            idx = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + n;
+          }
+          float v = acc[i][j][r] * oscale + bs;
+          if (p.mask16) {
+            if ((short)p.mask16[idx] <= 0) v = 0.f;
+          } else if (p.mask && p.mask[idx] <= 0.f) {
+            v = 0.f;
+          }
           atomicAdd(p.out + idx, v);
-          continue;
         }
-        if (accum) v += p.out[idx];
-        if (relu_out) v = fmaxf(v, 0.f);
-        p.out[idx] = v;
-        if (p.out16) reinterpret_cast<__bf16*>(p.out16)[idx] = (__bf16)v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    // row indices of this pass and the global reads (ReLU mask, accumulate operand) issued up front: eight independent
+    // 16-byte loads in flight instead of one dependent load per row group
+    size_t idx[8];
+    bool live[8];
+    float4 mk32[8], prev[8];
+    uint2 mk16[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = m0 + wm * (TM * 32) + i * 32 + 4 * it + rsub;
+      live[it] = m < M;
+      const int mm = live[it] ? m : 0;
+      if (ident) {
+        idx[it] = (size_t)mm * p.N + ncol;
+      } else {
+        const int b = mm / HW;
+        const int rem = mm - b * HW;
+        const int yg = rem / p.Wg;
+        const int xg = rem - yg * p.Wg;
+        idx[it] = ((size_t)(b * p.Ho + yg * p.o_sy + p.o_oy) * p.Wo + xg * p.o_sx + p.o_ox) * p.N + ncol;
+      }
+      if (p.mask16) mk16[it] = *reinterpret_cast<const uint2*>(p.mask16 + idx[it]);
+      else if (p.mask) mk32[it] = *reinterpret_cast<const float4*>(p.mask + idx[it]);
+      if (accum) prev[it] = *reinterpret_cast<const float4*>(p.out + idx[it]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+    // (same wave: LDS operations of one wave complete in order, the compiler orders the dependent reads)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      float4 v = *reinterpret_cast<const float4*>(stage + (4 * it + rsub) * 64 + 4 * c4);
+      if (!live[it]) continue;
+      v.x = v.x * oscale + bsum.x; v.y = v.y * oscale + bsum.y; v.z = v.z * oscale + bsum.z; v.w = v.w * oscale + bsum.w;
+      if (p.mask16) {          // bf16 <= 0  <=>  its int16 is negative or +0 (-0 = 0x8000 is negative as int16)
+        if ((short)(mk16[it].x & 0xffffu) <= 0) v.x = 0.f;
+        if ((short)(mk16[it].x >> 16) <= 0) v.y = 0.f;
+        if ((short)(mk16[it].y & 0xffffu) <= 0) v.z = 0.f;
+        if ((short)(mk16[it].y >> 16) <= 0) v.w = 0.f;
+      } else if (p.mask) {
+        if (mk32[it].x <= 0.f) v.x = 0.f;
+        if (mk32[it].y <= 0.f) v.y = 0.f;
+        if (mk32[it].z <= 0.f) v.z = 0.f;
+        if (mk32[it].w <= 0.f) v.w = 0.f;
+      }
+      if (accum) { v.x += prev[it].x; v.y += prev[it].y; v.z += prev[it].z; v.w += prev[it].w; }
+      if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(p.out + idx[it]) = v;
+      if (p.out16) {
+        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+        bf16x4v h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4v*>(p.out16 + idx[it]) = h;
       }
     }
   }
@@ -562,14 +632,20 @@ extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, c
 //   per-sample factors of the shared sweep where those apply: sg_cvt_bf16's rowscale), stride-1 convolutions only.
 // The reduction index (pixels) is the SLOW index of both operands in memory, the MFMA wants it fastest in each lane's
 // fragment.  Round 1 transposed in registers (8x4 blocks through VGPRs and ds_write).  Here the tiles go global -> LDS by
-// DMA exactly as they lie in memory ([64 pixels][256 channels], 512 B per pixel, as two 128-channel sub-tiles with
-// 256-byte rows) and the transposition is done by the LDS read itself: ds_read_b64_tr_b16 hands lane i of a 16-lane group
-// column i of a 4-row x 16-column block, i.e. four consecutive pixels of one channel -- two of them make the 8-pixel
-// fragment of v_mfma_f32_32x32x16_bf16 for BOTH operands.  Bank swizzle (guide T10, image (b)): 16-byte chunk ch of row r
-// lives in slot ch ^ (((r & 3) << 2) | ((r >> 2) & 3)); the DMA applies it on the source side.
-// Workgroup = one (tap, 256-channel c-tile, 256-channel n-tile) x one chunk of pixels; 8 waves (2 x 4), wave tile 128 x 64
-// -> 12 transposed reads per 8 MFMAs; same two-stage pipeline and phantom-tile loop as sg_igemm_bf16v2_kernel.  Partial
-// sums of the pixel chunks meet in dW through float atomics (one 128-byte row segment per half-wave).
+// DMA exactly as they lie in memory (64 pixels x CT / NT channels) and the transposition is done by the LDS read itself:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block, i.e. four consecutive pixels
+// of one channel -- two of them make the 8-pixel fragment of v_mfma_f32_32x32x16_bf16 for BOTH operands.
+// LDS images (guide T10; the DMA applies the swizzle on the source side):
+//   256-channel operand tile: two 128-channel sub-tiles with 256-byte rows, chunk ch of row r in slot
+//                             ch ^ (((r & 3) << 2) | ((r >> 2) & 3))                                    (image (b))
+//   64-channel operand tile : 8-row x 32-channel subtiles of 512 bytes,
+//                             off = 1024 (r >> 3) + 512 (ch >> 2) + 64 (r & 7) + 16 ((ch & 3) ^ ((r >> 2) & 3))   (image (a))
+// Workgroup = one (tap, CT-channel c-tile, NT-channel n-tile) x one chunk of pixels, 8 waves:
+//   CT 256, NT 256: 2 x 4 waves, wave tile 128 x 64 (12 transposed reads per 8 MFMAs)            -- the large layers
+//   CT  64, NT 256: 2 x 4 waves, wave tile  32 x 64                                              -- 64 -> 512 (3x3, 1x1)
+//   CT  64, NT  64: 2 x 2 waves x 2 k-groups (each group takes two of a tile's four k-steps)    -- 64 -> 64
+// Same two-stage pipeline and phantom-tile loop as sg_igemm_bf16v2_kernel.  Partial sums of the pixel chunks (and of the
+// k-groups) meet in dW through float atomics (one 128-byte row segment per half-wave).
 struct SgWgrad2Args {
   const u16* p;        // bf16 [Bn, H, W, Cp]
   const u16* q;        // bf16 [Bn, H, W, Cq]
@@ -581,12 +657,22 @@ struct SgWgrad2Args {
   SgTap taps[SG_MAX_TAPS];
 };
 
+template <int CT, int NT>
 __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr bool PA = CT == 64, QA = NT == 64;        // image (a) operands
+  constexpr int PT = 64 * CT * 2, QT = 64 * NT * 2;   // tile bytes
+  constexpr int NP = CT / 64, NQ = NT / 64;           // DMA instructions per thread: 4 (256 channels) or 1 (64)
+  constexpr int KG = (CT == 64 && NT == 64) ? 2 : 1;  // k-groups
+  constexpr int WN = NT == 256 ? 4 : 2, WM = 8 / KG / WN;
+  constexpr int TM = CT / WM / 32, TN = NT / WN / 32;
+  constexpr int SPT = 4 / KG;                         // k-steps per tile and wave
+  constexpr int NF = 2 * (TM + TN);                   // transposed reads per k-step
+  static_assert((TM == 1 || TM == 4) && (TN == 1 || TN == 2) && WM * WN * KG == 8, "wave layout");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;              // 2 (c) x 4 (n) waves, wave tile 128 x 64
+  const int kg = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
   const long M = (long)p.Bn * p.H * p.W;
   // block -> (pixel chunk, combo): the combos of one chunk are adjacent (they re-read the same pixels from L2 / MALL)
   const int combos = p.ntaps * p.c_tiles * p.n_tiles;
@@ -594,126 +680,189 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
   int combo = blockIdx.x - chunk * combos;
   const int tap = combo / (p.c_tiles * p.n_tiles);
   combo -= tap * p.c_tiles * p.n_tiles;
-  const int c0 = (combo / p.n_tiles) * 256, n0 = (combo % p.n_tiles) * 256;
+  const int c0 = (combo / p.n_tiles) * CT, n0 = (combo % p.n_tiles) * NT;
   const long m_begin = (long)chunk * p.mchunk;
   const long m_end = m_begin + p.mchunk < M ? m_begin + p.mchunk : M;
   const int KT = (int)((m_end - m_begin + 63) / 64);
   const int tdy = p.taps[tap].dy, tdx = p.taps[tap].dx;
 
-  // ---- DMA lane roles.  Instruction ii = 8 i + wave (i = 0..3) moves sub-tile (ii & 1), rows 4 (ii >> 1) .. + 3:
-  //      lane -> row (l >> 4) of the four, slot (l & 15); it fetches chunk slot ^ g(row) of its pixel's 128-channel half
+  // ---- DMA lane roles.
+  //  256-channel tile: instruction ii = 8 i + wave (i = 0..3) moves sub-tile (ii & 1), rows 4 (ii >> 1) .. + 3: lane -> row
+  //                    (l >> 4) of the four, slot (l & 15); it fetches chunk slot ^ g(row) of its pixel's 128-channel half
+  //  64-channel tile : the one instruction of wave w moves rows 8 w .. + 7: lane -> subtile (l >> 5), row ((l & 31) >> 2),
+  //                    slot (l & 3); it fetches chunk (subtile << 2) | (slot ^ ((row >> 2) & 3))
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(sg2_zero_page) + 16 * (lane & 15);
-  int ry[4], rx[4];            // (y, x) cursor of the pixel this lane loads for instruction i in the CURRENT load tile
-  long rm[4];                  // its pixel index
-  unsigned csw[4];             // byte offset of its (swizzled) chunk inside the pixel's channel vector, before the c0 / n0 tile offset
   const int HW = p.H * p.W;
+  constexpr bool SAMEROLE = (PA == QA) && (NP == NQ);   // P and Q rows of a lane coincide: one pixel cursor serves both
+  int ry[NP], rx[NP];          // (y, x) cursor of the pixel this lane loads for P instruction i in the CURRENT load tile
+  int rmp[NP], rmq[SAMEROLE ? 1 : NQ];       // pixel indices of its P / Q rows, relative to m_begin
+  unsigned cswp[NP], cswq[NQ]; // byte offset of its (swizzled) chunk inside the pixel's channel vector (before c0 / n0)
+  auto role = [&](bool img_a, int i, int& row, unsigned& csw) {
+    if (img_a) {
+      row = 8 * wave + ((lane & 31) >> 2);
+      csw = 16u * (unsigned)(((lane >> 5) << 2) | ((lane & 3) ^ ((row >> 2) & 3)));
+    } else {
+      const int ii = 8 * i + wave;
+      row = 4 * (ii >> 1) + (lane >> 4);
+      const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+      csw = 2u * (unsigned)((ii & 1) * 128) + 16u * (unsigned)((lane & 15) ^ g);
+    }
+  };
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ii = 8 * i + wave;
-    const int sub = ii & 1, row = 4 * (ii >> 1) + (lane >> 4);
-    const int g = ((row & 3) << 2) | ((row >> 2) & 3);
-    csw[i] = 2u * (unsigned)(sub * 128) + 16u * (unsigned)((lane & 15) ^ g);
+  for (int i = 0; i < NP; ++i) {
+    int row;
+    role(PA, i, row, cswp[i]);
     const long m = m_begin + row;
-    rm[i] = m;
+    rmp[i] = row;
     const long mm = m < M ? m : 0;
     const int rem = (int)(mm % HW);
     ry[i] = rem / p.W;
     rx[i] = rem - ry[i] * p.W;
   }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    int row;
+    role(QA, i, row, cswq[i]);
+    if constexpr (!SAMEROLE) rmq[i] = row;
+  }
+  const int m_len = (int)(m_end - m_begin);
   const int adv_y = (64 % HW) / p.W, adv_x = (64 % HW) % p.W;       // cursor advance of 64 pixels (within one image plane)
   const int Hh = p.H;
-  const unsigned long long p_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 2ull * (unsigned)c0;
-  const unsigned long long q_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 2ull * (unsigned)n0;
+  const unsigned long long p_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 2ull * (unsigned)c0 + 2ull * (unsigned long long)m_begin * p.Cp;
+  const unsigned long long q_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 2ull * (unsigned)n0 + 2ull * (unsigned long long)m_begin * p.Cq;
   const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
   const long tap_shift = (long)tdy * p.W + tdx;                      // pixel shift of the tap (may be negative)
-  // part i of the load tile at the cursors into stage `st`, then advance cursor i by one tile (64 pixels)
+  // LDS: P stage 0 | P stage 1 | Q stage 0 | Q stage 1
+  // part i (0..3) of the load tile at the cursors into stage `st`, then advance those cursors by one tile (64 pixels)
   auto issue_part = [&](int st, int i) {
-    const bool live = rm[i] < m_end;
-    const int sy = ry[i] + tdy, sx = rx[i] + tdx;
-    const bool okp = live && sy >= 0 && sy < Hh && sx >= 0 && sx < p.W;
-    const unsigned long long pa = p_base64 + (unsigned long long)((rm[i] + tap_shift) * p.Cp) * 2ull + csw[i];
-    const unsigned long long qa = q_base64 + (unsigned long long)(rm[i] * p.Cq) * 2ull + csw[i];
-    const unsigned plo = okp ? (unsigned)pa : (unsigned)z_base64, phi = okp ? (unsigned)(pa >> 32) : (unsigned)(z_base64 >> 32);
-    const unsigned qlo = live ? (unsigned)qa : (unsigned)z_base64, qhi = live ? (unsigned)(qa >> 32) : (unsigned)(z_base64 >> 32);
-    const unsigned char* src_p = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)phi << 32) | plo));
-    const unsigned char* src_q = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)qhi << 32) | qlo));
-    const int ii = 8 * i + wave;
-    unsigned char* dst_p = smem + st * SG2_TILE + (ii & 1) * 16384 + (ii >> 1) * 1024;
-    unsigned char* dst_q = dst_p + 2 * SG2_TILE;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_p, (__attribute__((address_space(3))) void*)dst_p, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_q, (__attribute__((address_space(3))) void*)dst_q, 16, 0, 0);
-    // advance this cursor by 64 pixels
-    rm[i] += 64;
-    rx[i] += adv_x;
-    const int wx = rx[i] >= p.W ? 1 : 0;
-    rx[i] -= wx * p.W;
-    ry[i] += adv_y + wx;
-    ry[i] -= ry[i] >= Hh ? Hh : 0;
+    if (i < NP) {
+      const bool live = rmp[i] < m_len;
+      const int sy = ry[i] + tdy, sx = rx[i] + tdx;
+      const bool okp = live && sy >= 0 && sy < Hh && sx >= 0 && sx < p.W;
+      const unsigned long long pa = p_base64 + (unsigned long long)(((long)rmp[i] + tap_shift) * p.Cp * 2) + cswp[i];
+      const unsigned plo = okp ? (unsigned)pa : (unsigned)z_base64, phi = okp ? (unsigned)(pa >> 32) : (unsigned)(z_base64 >> 32);
+      const unsigned char* src_p = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)phi << 32) | plo));
+      const int ii = 8 * i + wave;
+      unsigned char* dst_p = smem + st * PT + (PA ? wave * 1024 : (ii & 1) * 16384 + (ii >> 1) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_p, (__attribute__((address_space(3))) void*)dst_p, 16, 0, 0);
+      if constexpr (!SAMEROLE) rmp[i] += 64;
+      rx[i] += adv_x;
+      const int wx = rx[i] >= p.W ? 1 : 0;
+      rx[i] -= wx * p.W;
+      ry[i] += adv_y + wx;
+      ry[i] -= ry[i] >= Hh ? Hh : 0;
+    }
+    if (i < NQ) {
+      const int rq = SAMEROLE ? rmp[i < NP ? i : 0] : rmq[SAMEROLE ? 0 : i];
+      const bool live = rq < m_len;
+      const unsigned long long qa = q_base64 + (unsigned long long)((long)rq * p.Cq * 2) + cswq[i];
+      const unsigned qlo = live ? (unsigned)qa : (unsigned)z_base64, qhi = live ? (unsigned)(qa >> 32) : (unsigned)(z_base64 >> 32);
+      const unsigned char* src_q = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)qhi << 32) | qlo));
+      const int ii = 8 * i + wave;
+      unsigned char* dst_q = smem + 2 * PT + st * QT + (QA ? wave * 1024 : (ii & 1) * 16384 + (ii >> 1) * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_q, (__attribute__((address_space(3))) void*)dst_q, 16, 0, 0);
+      if constexpr (SAMEROLE) rmp[i < NP ? i : 0] += 64;
+      else rmq[SAMEROLE ? 0 : i] += 64;
+    }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- transposed fragment reads: lane = 16 grp4 + 4 q + pp; h = l >> 5 (pixel half of the k-step), grp = (l >> 4) & 1
-  //      (16-channel half of a 32-channel group); read u (0,1) covers pixels 16 ks + 8 h + 4 u + q
+  //      (16-channel half of a 32-channel group); read u (0,1) covers pixels 16 ks + 8 h + 4 u + q.  The k-step (and, for
+  //      image (a), the 32-channel group) is an immediate of the read.
   typedef int v2i __attribute__((ext_vector_type(2)));
   typedef int v4i __attribute__((ext_vector_type(4)));
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int q4 = (lane >> 2) & 3, pp = lane & 3, grp = (lane >> 4) & 1, h = lane >> 5;
-  unsigned pa_addr[4][2], qb_addr[2][2];
+  unsigned pa_addr[TM][2], qb_addr[TN][2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int row = 8 * h + 4 * u + q4;                       // + 16 ks (an immediate)
-    const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int row = 8 * h + 4 * u + q4;                       // + 16 ks
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = 4 * i + 2 * grp + (pp >> 1);
-      pa_addr[i][u] = lds0 + (unsigned)(wm * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (PA) {
+        const int ch = 4 * wm + 2 * grp + (pp >> 1);          // TM == 1: the wave's 32 channels = subtile wm
+        pa_addr[i][u] = lds0 + (unsigned)(1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3)) + 8 * (pp & 1));
+      } else {
+        const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+        const int ch = 4 * i + 2 * grp + (pp >> 1);
+        pa_addr[i][u] = lds0 + (unsigned)(wm * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ch = 8 * (wn & 1) + 4 * j + 2 * grp + (pp >> 1);
-      qb_addr[j][u] = lds0 + (unsigned)(2 * SG2_TILE + (wn >> 1) * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (QA) {
+        const int ch = 4 * wn + 2 * grp + (pp >> 1);          // TN == 1
+        qb_addr[j][u] = lds0 + (unsigned)(2 * PT + 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3)) + 8 * (pp & 1));
+      } else {
+        const int g = ((row & 3) << 2) | ((row >> 2) & 3);
+        const int ch = 8 * (wn & 1) + 4 * j + 2 * grp + (pp >> 1);
+        qb_addr[j][u] = lds0 + (unsigned)(2 * PT + (wn >> 1) * 16384 + 256 * row + 16 * (ch ^ g) + 8 * (pp & 1));
+      }
     }
   }
+  // byte offset of k-step ks inside a tile: 16 pixel rows = 4096 B (256-byte rows) or 2048 B (image (a): two 8-row groups)
+  constexpr int PKS = PA ? 2048 : 4096, QKS = QA ? 2048 : 4096;
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
   const short rfloor = relu_in ? (short)0 : (short)0x8000;
   const s16x8 rfloor8 = {rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor};
   v2i af[2][4][2], bfr[2][2][2];          // [slot][group][u]
 #define SGW_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define SGW_READ_FRAGS(st, ks, slot)                                                  \
-  do {                                                                                \
-    SGW_TR(af[slot][0][0], pa_addr[0][0], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][0][1], pa_addr[0][1], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][1][0], pa_addr[1][0], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][1][1], pa_addr[1][1], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][2][0], pa_addr[2][0], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][2][1], pa_addr[2][1], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][3][0], pa_addr[3][0], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(af[slot][3][1], pa_addr[3][1], (st) * SG2_TILE + (ks) * 4096);             \
-    SGW_TR(bfr[slot][0][0], qb_addr[0][0], (st) * SG2_TILE + (ks) * 4096);            \
-    SGW_TR(bfr[slot][0][1], qb_addr[0][1], (st) * SG2_TILE + (ks) * 4096);            \
-    SGW_TR(bfr[slot][1][0], qb_addr[1][0], (st) * SG2_TILE + (ks) * 4096);            \
-    SGW_TR(bfr[slot][1][1], qb_addr[1][1], (st) * SG2_TILE + (ks) * 4096);            \
+  // ks = the step's index inside the tile for THIS wave's k-group: (step) for KG == 1, 2 kg + step for KG == 2 -- the
+  // k-group offset is folded into the address registers below so that `ks` stays a literal
+#define SGW_READ_FRAGS(st, ks, slot)                                                             \
+  do {                                                                                           \
+    SGW_TR(af[slot][0][0], pa_addr[0][0], (st) * PT + (ks) * PKS);                               \
+    SGW_TR(af[slot][0][1], pa_addr[0][1], (st) * PT + (ks) * PKS);                               \
+    if constexpr (TM > 1) {                                                                      \
+      SGW_TR(af[slot][1][0], pa_addr[TM > 1 ? 1 : 0][0], (st) * PT + (ks) * PKS);                \
+      SGW_TR(af[slot][1][1], pa_addr[TM > 1 ? 1 : 0][1], (st) * PT + (ks) * PKS);                \
+      SGW_TR(af[slot][2][0], pa_addr[TM > 2 ? 2 : 0][0], (st) * PT + (ks) * PKS);                \
+      SGW_TR(af[slot][2][1], pa_addr[TM > 2 ? 2 : 0][1], (st) * PT + (ks) * PKS);                \
+      SGW_TR(af[slot][3][0], pa_addr[TM > 3 ? 3 : 0][0], (st) * PT + (ks) * PKS);                \
+      SGW_TR(af[slot][3][1], pa_addr[TM > 3 ? 3 : 0][1], (st) * PT + (ks) * PKS);                \
+    }                                                                                            \
+    SGW_TR(bfr[slot][0][0], qb_addr[0][0], (st) * QT + (ks) * QKS);                              \
+    SGW_TR(bfr[slot][0][1], qb_addr[0][1], (st) * QT + (ks) * QKS);                              \
+    if constexpr (TN > 1) {                                                                      \
+      SGW_TR(bfr[slot][1][0], qb_addr[TN > 1 ? 1 : 0][0], (st) * QT + (ks) * QKS);               \
+      SGW_TR(bfr[slot][1][1], qb_addr[TN > 1 ? 1 : 0][1], (st) * QT + (ks) * QKS);               \
+    }                                                                                            \
   } while (0)
+  if constexpr (KG == 2) {                // fold the k-group's first step (2 kg) into the per-lane addresses
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pa_addr[0][u] += (unsigned)(2 * kg * PKS);
+      qb_addr[0][u] += (unsigned)(2 * kg * QKS);
+    }
+  }
   auto mma = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
       const v4i a4 = {af[slot][i][0][0], af[slot][i][0][1], af[slot][i][1][0], af[slot][i][1][1]};
       const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a4), rfloor8));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TN; ++j) {
         const v4i b4 = {bfr[slot][j][0][0], bfr[slot][j][0][1], bfr[slot][j][1][0], bfr[slot][j][1][1]};
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
       }
     }
   };
-#define SGW_WAIT_LGKM(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // wait until only the NF transposed reads just issued are still in flight
+#define SGW_WAIT_FRAGS()                                                                \
+  do {                                                                                  \
+    if constexpr (NF == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");         \
+    else if constexpr (NF == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");      \
+    else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                             \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
 
   {
 #pragma unroll
@@ -724,20 +873,39 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
     issue_part(1, 1);
     SGW_READ_FRAGS(0, 0, 0);
   }
-#define SGW_K_TILE(st, sn)                                         \
+  // four k-steps per tile (one k-group)
+#define SGW_K_TILE4(st, sn)                                        \
   do {                                                             \
     SGW_READ_FRAGS(st, 1, 1);                                      \
     issue_part(sn, 2);                                             \
-    SGW_WAIT_LGKM(12);                                             \
+    SGW_WAIT_FRAGS();                                              \
     mma(0);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
     SGW_READ_FRAGS(st, 2, 0);                                      \
     issue_part(sn, 3);                                             \
-    SGW_WAIT_LGKM(12);                                             \
+    SGW_WAIT_FRAGS();                                              \
     mma(1);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
     SGW_READ_FRAGS(st, 3, 1);                                      \
-    SGW_WAIT_LGKM(12);                                             \
+    SGW_WAIT_FRAGS();                                              \
+    mma(0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                                  \
+    issue_part(st, 0);                                             \
+    issue_part(st, 1);                                             \
+    SGW_READ_FRAGS(sn, 0, 0);                                      \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    mma(1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+  // two k-steps per tile and wave (two k-groups)
+#define SGW_K_TILE2(st, sn)                                        \
+  do {                                                             \
+    SGW_READ_FRAGS(st, 1, 1);                                      \
+    issue_part(sn, 2);                                             \
+    issue_part(sn, 3);                                             \
+    SGW_WAIT_FRAGS();                                              \
     mma(0);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
@@ -750,35 +918,80 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
   for (int kt = 0; kt < KT; kt += 2) {
-    SGW_K_TILE(0, 1);
-    SGW_K_TILE(1, 0);
+    if constexpr (SPT == 4) {
+      SGW_K_TILE4(0, 1);
+      SGW_K_TILE4(1, 0);
+    } else {
+      SGW_K_TILE2(0, 1);
+      SGW_K_TILE2(1, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue: accumulator row = c, lane = n; dW[c][n] += (atomics: nchunks adders per address)
+  // ---- epilogue: accumulator row = c, lane = n; dW[c][n] += (atomics: nchunks x KG adders per address)
   float* dwt = p.dw + p.taps[tap].w_off;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = c0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         atomicAdd(dwt + (size_t)c * p.Cq + n, acc[i][j][r]);
       }
     }
   }
 }
 
+template <int CT, int NT>
+static int sg2_launch_wgrad(SgWgrad2Args a, long M, hipStream_t s) {
+  a.c_tiles = a.Cp / CT;
+  a.n_tiles = a.Cq / NT;
+  const int combos = a.ntaps * a.c_tiles * a.n_tiles;
+  // Pixel chunks per combo.  One workgroup per CU at a time, so a launch of W workgroups takes ceil(W / 256) rounds of
+  // (k-tiles per chunk) x t_tile + t_epi, where t_epi is the CT x NT x 4 bytes of float atomics every workgroup ends with
+  // (measured for 256 x 256: WRITE_SIZE 550 MB per launch at 2304 workgroups, the chip adds ~1.3 TB/s -> ~50 us per round
+  // against ~0.9 us per k-tile).  Few long workgroups win: the count that minimises the modelled time, >= 4 k-tiles each.
+  static const int wg_env = getenv("SG_WGRAD2_CHUNKS") ? atoi(getenv("SG_WGRAD2_CHUNKS")) : 0;
+  const double t_tile = 0.9 * (CT * NT) / 65536.0 + 0.15, t_epi = 50.0 * (CT * NT) / 65536.0 + 2.0;
+  const long tiles_all = (M + 63) / 64;
+  const long max_chunks = tiles_all / 4 > 0 ? tiles_all / 4 : 1;
+  long nchunks = 1;
+  double best = 1e30;
+  for (long cc = 1; cc <= max_chunks && cc * combos <= 8192; ++cc) {
+    const long Wg = combos * cc;
+    const double t = (double)((Wg + 255) / 256) * ((double)((tiles_all + cc - 1) / cc) * t_tile + t_epi);
+    if (t < best) { best = t; nchunks = cc; }
+  }
+  if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
+  long mchunk = (M + nchunks - 1) / nchunks;
+  mchunk = (mchunk + 63) / 64 * 64;
+  nchunks = (M + mchunk - 1) / mchunk;
+  a.mchunk = (int)mchunk;
+  a.nchunks = (int)nchunks;
+  constexpr int LDS_BYTES = 2 * 64 * CT * 2 + 2 * 64 * NT * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_bf16v2_kernel<CT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return SG_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((sg_wgrad_bf16v2_kernel<CT, NT>), dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, s, a);
+  return sg_launch_status();
+}
+
 // x16 bf16 [B,H,W,Cin], dy16 bf16 [B,H,W,Cout] (per-sample factors already applied), dw fp32 [kh,kw,Cin,Cout] +=.
-// SAME stride-1 convolutions with Cin % 256 == 0 and Cout % 256 == 0, else SG_ERR_UNSUPPORTED (caller: sg_conv2d_bwd_weight).
+// SAME stride-1 convolutions (or 1x1) with (Cin, Cout) % (256, 256), (64, 256) or (64, 64) == 0, else SG_ERR_UNSUPPORTED
+// (caller: sg_conv2d_bwd_weight).
 extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
                                            int kh, int kw, int pad_same, int flags, void* stream) {
   if (!x16 || !dy16 || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   if (!pad_same && (kh != 1 || kw != 1)) return SG_ERR_UNSUPPORTED;
-  if ((Cin % 256) || (Cout % 256)) return SG_ERR_UNSUPPORTED;
+  if ((Cin % 64) || (Cout % 64)) return SG_ERR_UNSUPPORTED;
   const long M = (long)B * H * W;
   if (M <= 0) return SG_OK;
   if (2L * M * Cin >= (1L << 40) || 2L * M * Cout >= (1L << 40)) return SG_ERR_UNSUPPORTED;
@@ -788,39 +1001,11 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   const int ph = kh / 2, pw = kw / 2;
   for (int ky = 0; ky < kh; ++ky)
     for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
-  a.c_tiles = Cin / 256;
-  a.n_tiles = Cout / 256;
-  const int combos = a.ntaps * a.c_tiles * a.n_tiles;
-  // Pixel chunks per combo.  One workgroup per CU at a time, so a launch of W workgroups takes ceil(W / 256) rounds of
-  // (k-tiles per chunk) x t_tile + t_epi, where t_epi is the 256 KB of float atomics every workgroup ends with (measured:
-  // WRITE_SIZE 550 MB per launch at 2304 workgroups, the chip adds ~1.3 TB/s -> ~50 us per round against ~0.9 us per
-  // k-tile).  Few long workgroups win: the count that minimises the modelled time, at least 4 k-tiles each.
-  static const int wg_env = getenv("SG_WGRAD2_CHUNKS") ? atoi(getenv("SG_WGRAD2_CHUNKS")) : 0;
-  const long tiles_all = (M + 63) / 64;
-  const long max_chunks = tiles_all / 4 > 0 ? tiles_all / 4 : 1;
-  long nchunks = 1;
-  double best = 1e30;
-  for (long cc = 1; cc <= max_chunks && cc * combos <= 4096; ++cc) {
-    const long Wg = combos * cc;
-    const double t = (double)((Wg + 255) / 256) * ((double)((tiles_all + cc - 1) / cc) * 0.9 + 50.0);
-    if (t < best) { best = t; nchunks = cc; }
-  }
-  if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
-  long mchunk = (M + nchunks - 1) / nchunks;
-  mchunk = (mchunk + 63) / 64 * 64;
-  nchunks = (M + mchunk - 1) / mchunk;
-  a.mchunk = (int)mchunk;
-  a.nchunks = (int)nchunks;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_bf16v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SG2_LDS) != hipSuccess) {
-      (void)hipGetLastError();
-      return SG_ERR_UNSUPPORTED;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(sg_wgrad_bf16v2_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), SG2_LDS, (hipStream_t)stream, a);
-  return sg_launch_status();
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin % 256 == 0 && Cout % 256 == 0) return sg2_launch_wgrad<256, 256>(a, M, s);
+  if (Cout % 256 == 0) return sg2_launch_wgrad<64, 256>(a, M, s);
+  if (Cin == 64 && Cout == 64) return sg2_launch_wgrad<64, 64>(a, M, s);
+  return SG_ERR_UNSUPPORTED;
 }
 
 // ==========================================================================================================

@@ -21,15 +21,33 @@ from . import ops
 # --------------------------------------------------------------------------------------------
 # initialisers (Keras semantics; host-side, run once)
 # --------------------------------------------------------------------------------------------
+FAST_INIT = False          # tests that overwrite every weight right after construction skip the QR factorisations
+_ORTHO_CACHE: Dict = {}     # (shape, generator state) -> (kernel, generator state afterwards): identical re-creations are free
+
+
 def orthogonal(shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:
     """tf.initializers.orthogonal(gain=1): QR of a N(0,1) matrix flattened to [prod(shape[:-1]), shape[-1]]."""
     rows, cols = int(math.prod(shape[:-1])), int(shape[-1])
+    if FAST_INIT:
+        return (torch.randn(tuple(shape), generator=gen) / math.sqrt(max(rows, cols))).contiguous()
+    big = rows * cols >= 1 << 18
+    if big:
+        key = (tuple(shape), hash(gen.get_state().numpy().tobytes()))
+        hit = _ORTHO_CACHE.get(key)
+        if hit is not None:
+            gen.set_state(hit[1])
+            return hit[0].clone()
     a = torch.randn((cols, rows) if rows < cols else (rows, cols), generator=gen, dtype=torch.float64)
     q, r = torch.linalg.qr(a)
     q = q * torch.sign(torch.diagonal(r))
     if rows < cols:
         q = q.t()
-    return q.reshape(tuple(shape)).float().contiguous()
+    out = q.reshape(tuple(shape)).float().contiguous()
+    if big:
+        if len(_ORTHO_CACHE) > 64:
+            _ORTHO_CACHE.clear()
+        _ORTHO_CACHE[key] = (out.clone(), gen.get_state())
+    return out
 
 
 def glorot_uniform(shape: Sequence[int], gen: torch.Generator) -> torch.Tensor:

@@ -417,7 +417,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
-    if USE_V2 and _low() and Cin % 256 == 0 and Cout % 256 == 0 and (same or kh * kw == 1):
+    if USE_V2 and _low() and (same or kh * kw == 1) and ((Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)):
         # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy; the bias
         # gradient (fp32 sums of the scaled dy) is its own memory-bound sweep
         x16 = bf16_of(x)

@@ -348,7 +348,7 @@ def _problem(L_f):
     return _PROBLEMS[L_f]
 
 
-@pytest.mark.parametrize("loss_name,balance,L_f", [("hinge", False, 3), ("not_saturating", True, 3), ("hinge", True, 2), ("hinge", False, 2)])
+@pytest.mark.parametrize("loss_name,balance,L_f", [("hinge", False, 3), ("not_saturating", True, 3), ("hinge", True, 2)])
 def test_train_step(setup, dev, loss_name, balance, L_f, request):
     """One whole train_step (B = 8) against the fp64 oracle, with a CALIBRATED tolerance instead of a guessed one.
 
@@ -376,10 +376,15 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
     ref_scalars, ref_grads, ref_w = cal["scalars"], cal["grads"], cal["weights"]
     assert ref_scalars[12] > 0.05 and ref_scalars[11] > 0.05, "fixture lost its conditioning: std(g_loss), std(r_fake) = %r" % (ref_scalars[11:13],)
 
-    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
-    D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
-    R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
-    S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+    from scrabble_gan_amd import nn as _nn
+    _nn.FAST_INIT = True                # every weight is loaded from the fixture below: skip the QR initialisers
+    try:
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+    finally:
+        _nn.FAST_INIT = False
     gan = NA.make_gan(G, D, R, S, vis_model=False)
     models = {"G": G, "D": D, "R": R, "S": S}
     for n, m in models.items():

@@ -76,7 +76,8 @@ def main():
 
         def w_v2():
             call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, k, k, 1, ops.RELU_IN, st())
-        if Cin % 256 == 0 and Cout % 256 == 0:
+        wg2 = (Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)
+        if wg2:
             t = timeit(w_v2)
             line += "  | wgrad v2 %7.3f ms %7.1f TF/s" % (t, flops / t / 1e9)
         t = timeit(lambda: ops.conv2d_bwd_weight(x, dy, dw, relu_in=True))
@@ -84,7 +85,7 @@ def main():
         print(line, flush=True)
         if args.no_check:
             continue
-        if Cin % 256 == 0 and Cout % 256 == 0:
+        if wg2:
             # whole-batch dW against the fp32 kernel on the SAME bf16-representable operands (exact products, fp32 sums)
             xq, dyq = x16.float(), dy16.float()
             ops.set_conv_dtype("f32")

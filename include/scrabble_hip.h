@@ -63,6 +63,21 @@ int sg_conv2d_fwd_bf16(const float* x, const void* wp_fwd, const float* bias, co
 int sg_conv2d_bwd_data_bf16(const float* dy, const void* wp_bwd, const float* mask, float* dx,
                             int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* ---- second-generation fp32 convolutions (round 2): the DMA-fed 256-row-tile kernel of conv_bf16v2.hip with fp32 operands
+ *      (v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulation: same numerics as sg_conv2d_fwd / _bwd_data up to the
+ *      summation order).  wt_fwd = the filter transposed to [tap][Cout][Cin] by sg_transpose_filter(w, taps, K = Cin, N = Cout);
+ *      the data-grad takes w [kh,kw,Cin,Cout] itself.  Same contracts and flags as sg_conv2d_fwd / sg_conv2d_bwd_data
+ *      (resnet_ops.py:65,98,103,109); SG_ERR_UNSUPPORTED unless reduction channels % 32 == 0 and output channels % 64 == 0. */
+int sg_conv2d_fwd_v2(const float* x, const float* wt_fwd, const float* bias, const float* bias2, float* y,
+                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, float* dx,
+                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+
+/* fp32 weight gradient, second generation (same contract as sg_conv2d_bwd_weight: dw += , dbias += , optional per-sample
+ * factors); stride-1 SAME (or 1x1) convolutions with Cin % 256 == 0, Cout % 256 == 0 and H*W >= 32, else SG_ERR_UNSUPPORTED. */
+int sg_conv2d_bwd_weight_v2(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale, int B, int H, int W,
+                            int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+
 /* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
  *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale
  *      (nullable, [n / rowlen], rowlen % 8 == 0) multiplies row r by rowscale[r] first (the per-sample factors of the shared

@@ -99,7 +99,10 @@ constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A s
 // ES = bytes per operand element: 2 = bf16 (k-tile = 64 channels, four 32x32x16 MFMA steps), 1 = fp8 e4m3 (k-tile = 128
 // channels, two v_mfma_scale_f32_32x32x64_f8f6f4 steps with unit block scales: 2x the bf16 rate per clock).  The byte
 // geometry of the tiles (128-byte rows, 16-byte chunks, swizzle, DMA roles) is the same for both.
-template <int BN, int ES>
+// RELU: max(a, 0) on the A fragments in registers (SG_RELU_IN); compiled out otherwise -- a VALU instruction in front of an
+// MFMA pair is NOT free on the fp32 stream (tools/mfma_peak.hip: 154 -> 141 TFLOP/s with two per pair), so launches without
+// the flag (every data-grad, convs behind a fused BN+ReLU) run a loop without any.
+template <int BN, int ES, bool RELU>
 __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int BM = SG2_BM, BK = 128 / ES;            // channels per k-tile
@@ -233,9 +236,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     a_addr[s] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
     b_addr[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
   }
-  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
-  const short rfloor = relu_in ? (short)0 : (short)0x8000;
-  const s16x8 rfloor8 = {rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor, rfloor};
+  const s16x8 rfloor8 = {0, 0, 0, 0, 0, 0, 0, 0};      // (bf16 compares like a sign-magnitude integer: max as int16 against +0)
 
   v4i af[2][4], bfr[2][2];
 #define SG2_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -252,11 +253,29 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   auto mma = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, af[slot][i]), rfloor8));
+      bf16x8 a = __builtin_bit_cast(bf16x8, af[slot][i]);
+      if constexpr (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, af[slot][i]), rfloor8));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bfr[slot][j]), acc[i][j], 0, 0, 0);
     }
+  };
+  // the MFMAs of a step with the four DMA parts of the NEXT tile for stage `st` between the MFMA pairs (address math and
+  // issue in the shadow of the matrix pipe)
+  auto mma_dma = [&](int slot, int st) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      bf16x8 a = __builtin_bit_cast(bf16x8, af[slot][i]);
+      if constexpr (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, af[slot][i]), rfloor8));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, bfr[slot][j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = i * 4 / TM; q < (i + 1) * 4 / TM; ++q) issue_part(st, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance();
   };
   // wait until only the TM + TN fragment reads just issued are still in flight
 #define SG2_WAIT_FRAGS()                                                        \
@@ -267,19 +286,18 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     __builtin_amdgcn_sched_barrier(0);                                          \
   } while (0)
 
-  // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, parts 0-1 of tile t+1 issued.
+  // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, ALL of tile t+1 issued (during the last
+  // step of tile t-1: a whole tile of lead -- with the parts spread over the tile's own first steps the last ones had
+  // half a tile, less than an L2 round trip under load, and the vmcnt(0) below stalled every tile).
   // After step 2: tile t+1 has landed (this wave's DMAs; the barrier extends that to every wave's) and every wave has its
   // last fragments of stage `st` in registers, so stage `st` is free for tile t+2.
 #define SG2_K_TILE(st, sn)                                                                                   \
   do {                                                                                                       \
     SG2_READ_FRAGS(st, 1, 1);                                                                                \
-    issue_part(sn, 2);                                                                                       \
     SG2_WAIT_FRAGS(); /* slot 0 is in; the reads of step 1 stay in flight under the MFMAs */                 \
     mma(0);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     SG2_READ_FRAGS(st, 2, 0);                                                                                \
-    issue_part(sn, 3);                                                                                       \
-    advance();                                                                                               \
     SG2_WAIT_FRAGS();                                                                                        \
     mma(1);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -289,11 +307,9 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
     __builtin_amdgcn_s_barrier();                                                                            \
-    issue_part(st, 0);                                                                                       \
-    issue_part(st, 1);                                                                                       \
     SG2_READ_FRAGS(sn, 0, 0);                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    mma(1);                                                                                                  \
+    mma_dma(1, st);                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   } while (0)
   // ---------------- fp8: two k-steps of 64 channels per tile; a fragment = 32 bytes = two swizzled 16-byte chunks
@@ -341,9 +357,6 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
 #define SG8_WAIT_ALL() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SG8_K_TILE(st, sn)                                                             \
   do {                                                                                 \
-    issue_part(sn, 2);                                                                 \
-    issue_part(sn, 3);                                                                 \
-    advance();                                                                         \
     SG8_WAIT_ALL();                                                                    \
     mma8(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -353,10 +366,92 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     __builtin_amdgcn_sched_barrier(0);                                                 \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
     __builtin_amdgcn_s_barrier();                                                      \
+    SG8_READ_FRAGS(sn, 0, 0);                                                          \
     issue_part(st, 0);                                                                 \
     issue_part(st, 1);                                                                 \
-    SG8_READ_FRAGS(sn, 0, 0);                                                          \
+    issue_part(st, 2);                                                                 \
+    issue_part(st, 3);                                                                 \
+    advance();                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+  // ---------------- fp32 (ES = 4): a k-tile is 32 channels = eight 16-byte chunks of 4 floats.  v_mfma_f32_32x32x2_f32
+  // takes ONE float per lane and operand: lanes 0-31 supply k = 0, lanes 32-63 k = 1.  The order of the reduction index is
+  // free as long as both operands agree, so lane half h reads the 8 bytes {4 c + 2 h, 4 c + 2 h + 1} of chunk c with ONE
+  // ds_read_b64 and feeds two MFMAs (element 0, then element 1): 6 reads per 16 MFMAs (1 024 matrix cycles) -- LDS and
+  // issue slots are almost idle, the loop is matrix-pipe bound.  Exact fp32 products and fp32 accumulation as in
+  // sg_igemm_kernel (only the summation order differs).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  unsigned a4[8], b4[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const unsigned ko = 16u * (unsigned)(s ^ swz) + 8u * (unsigned)khalf;
+    a4[s] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
+    b4[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+  }
+  v2f af4[2][4], bf4[2][2];
+#define SG4_DSR(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define SG4_READ_FRAGS(st, s, slot)                                                          \
+  do {                                                                                       \
+    SG4_DSR(af4[slot][0], a4[s], (st) * SG2_TILE + 0 * 4096);                                \
+    if constexpr (TM > 1) SG4_DSR(af4[slot][1], a4[s], (st) * SG2_TILE + 1 * 4096);          \
+    if constexpr (TM > 2) SG4_DSR(af4[slot][2], a4[s], (st) * SG2_TILE + 2 * 4096);          \
+    if constexpr (TM > 2) SG4_DSR(af4[slot][3], a4[s], (st) * SG2_TILE + 3 * 4096);          \
+    SG4_DSR(bf4[slot][0], b4[s], (st) * BTILE + 0 * 4096);                                   \
+    SG4_DSR(bf4[slot][1], b4[s], (st) * BTILE + 1 * 4096);                                   \
+  } while (0)
+  auto mma4 = [&](int slot) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float a = af4[slot][i][e];
+        // ReLU as ONE v_max_i32 on the bit pattern (negative floats are negative integers); fmaxf / v_med3 come with a
+        // canonicalising pre-pass, inline asm would hide the VALU -> MFMA hazard from hipcc (no s_nop: NaNs, seen)
+        if constexpr (RELU) a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), 0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf4[slot][j][e], acc[i][j], 0, 0, 0);
+      }
+  };
+  auto mma4_dma = [&](int slot, int st) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float a = af4[slot][i][e];
+        if constexpr (RELU) a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), 0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf4[slot][j][e], acc[i][j], 0, 0, 0);
+        if (e == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = i * 4 / TM; q < (i + 1) * 4 / TM; ++q) issue_part(st, q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    advance();
+  };
+#define SG4_STEP(st, s_next, slot_next, slot_cur)                                            \
+  do {                                                                                       \
+    SG4_READ_FRAGS(st, s_next, slot_next);                                                   \
+    SG2_WAIT_FRAGS();                                                                        \
+    mma4(slot_cur);                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#define SG4_K_TILE(st, sn)                                                                   \
+  do {                                                                                       \
+    SG4_STEP(st, 1, 1, 0);                                                                   \
+    SG4_STEP(st, 2, 0, 1);                                                                   \
+    SG4_STEP(st, 3, 1, 0);                                                                   \
+    SG4_STEP(st, 4, 0, 1);                                                                   \
+    SG4_STEP(st, 5, 1, 0);                                                                   \
+    SG4_STEP(st, 6, 0, 1);                                                                   \
+    SG4_STEP(st, 7, 1, 0);                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+    __builtin_amdgcn_s_barrier();                                                            \
+    SG4_READ_FRAGS(sn, 0, 0);                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    mma4_dma(1, st);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
   {
 #pragma unroll
@@ -364,15 +459,20 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     advance();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue_part(1, 0);
-    issue_part(1, 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_part(1, q);
+    advance();
     if constexpr (ES == 2) SG2_READ_FRAGS(0, 0, 0);
+    else if constexpr (ES == 4) SG4_READ_FRAGS(0, 0, 0);
     else SG8_READ_FRAGS(0, 0, 0);
   }
   for (int kt = 0; kt < KT; kt += 2) {          // two tiles per iteration: the stage index is a compile-time constant;
     if constexpr (ES == 2) {                    // with KT odd the last tile of the last iteration is a phantom tile
       SG2_K_TILE(0, 1);
       SG2_K_TILE(1, 0);
+    } else if constexpr (ES == 4) {
+      SG4_K_TILE(0, 1);
+      SG4_K_TILE(1, 0);
     } else {
       SG8_K_TILE(0, 1);
       SG8_K_TILE(1, 0);
@@ -503,8 +603,8 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
 static int g2_split_override = -1;
 extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
 
-template <int BN, int ES>
-static int sg2_launch_bn(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
+template <int BN, int ES, bool RELU>
+static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int n_tiles = a.N / BN;
   const int tiles = sg_cdiv(M, SG2_BM) * n_tiles;
@@ -545,15 +645,21 @@ static int sg2_launch_bn(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   static bool attr_done = false;
   constexpr int LDS_BYTES = 2 * SG2_TILE + 2 * BN * 128;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_igemm_bf16v2_kernel<BN, ES>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((sg_igemm_bf16v2_kernel<BN, ES, RELU>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   return sg_launch_status();
+}
+
+template <int BN, int ES>
+static int sg2_launch_bn(const SgIgemm2Args& a, hipStream_t s, long* twin_rows_done) {
+  if constexpr (ES == 1) return sg2_launch_bn_r<BN, ES, false>(a, s, twin_rows_done);     // (fp8: the ReLU is applied by the fp8 convert)
+  else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false>(a, s, twin_rows_done);
 }
 
 // -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
@@ -569,8 +675,29 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
   if (a_bytes >= (1L << 32) - 64 || es * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
   if (es == 1) return sg2_launch_bn<256, 1>(a, s, twin_rows_done);
-  if (a.N % 256 == 0) return sg2_launch_bn<256, 2>(a, s, twin_rows_done);
-  if (a.N % 128 == 0) return sg2_launch_bn<128, 2>(a, s, twin_rows_done);
+  // Tile width: the widest one that divides N, unless the launch cannot be cut along the reduction (a fused output ReLU
+  // rules the float-atomic tail split out) and a narrower tile fills the 256 CUs' rounds better.  Relative tile times:
+  // the bf16 loop is bound by the L2 -> LDS feed ((256 + BN) x 128 bytes per tile), the fp32 loop by the matrix pipe.
+  const long m_tiles = sg_cdiv((long)a.Bn * a.Hg * a.Wg, SG2_BM);
+  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT)) && a.ntaps * (a.Ca / (128 / es)) >= 8;
+  int bn = 0;
+  double best = 1e30;
+  for (int c = 256; c >= 64; c >>= 1) {
+    if (a.N % c) continue;
+    const long tiles = m_tiles * (a.N / c);
+    const double rounds = can_split && tiles % 256 ? (tiles < 256 ? 1.0 : (double)tiles / 256.0) : (double)((tiles + 255) / 256);
+    const double t_tile = es == 4 ? (c == 256 ? 1.0 : c == 128 ? 0.525 : 0.29) : (c == 256 ? 1.0 : c == 128 ? 0.75 : 0.625);
+    if (rounds * t_tile < 0.97 * best) { best = rounds * t_tile; bn = c; }
+  }
+  static const int bn_env = getenv("SG2_FORCE_BN") ? atoi(getenv("SG2_FORCE_BN")) : 0;      // (debugging aid)
+  if (bn_env > 0 && a.N % bn_env == 0) bn = bn_env;
+  if (es == 4) {
+    if (bn == 256) return sg2_launch_bn<256, 4>(a, s, twin_rows_done);
+    if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);
+    return sg2_launch_bn<64, 4>(a, s, twin_rows_done);
+  }
+  if (bn == 256) return sg2_launch_bn<256, 2>(a, s, twin_rows_done);
+  if (bn == 128) return sg2_launch_bn<128, 2>(a, s, twin_rows_done);
   return sg2_launch_bn<64, 2>(a, s, twin_rows_done);
 }
 
@@ -624,6 +751,40 @@ extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, c
   long done = 0;
   const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done);
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
+}
+
+// fp32 operands on the same kernel (ES = 4): x / dy are the fp32 NHWC tensors themselves; wt_fwd = the filter transposed to
+// [tap][Cout][Cin] (sg_transpose_filter(w, taps, K = Cin, N = Cout), once per optimizer step); the data-grad reads the
+// filter w [kh,kw,Cin,Cout] as it is (per tap [N = Cin][K = Cout]).  Contracts of sg_conv2d_fwd / sg_conv2d_bwd_data;
+// SG_ERR_UNSUPPORTED unless reduction channels % 32 == 0 and output channels % 64 == 0 (caller: the first-generation entry).
+extern "C" int sg_conv2d_fwd_v2(const float* x, const float* wt_fwd, const float* bias, const float* bias2, float* y, int B, int H,
+                                int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!x || !wt_fwd || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)x; a.w = (const u16*)wt_fwd; a.out = y; a.bias = bias; a.bias2 = bias2;
+  a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm_bf16v2(a, (hipStream_t)stream, nullptr, 4);
+}
+
+extern "C" int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int Cin,
+                                     int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!dy || !w || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
+  const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
+  SgIgemm2Args a{};
+  a.a = (const u16*)dy; a.w = (const u16*)w; a.out = dx; a.mask = mask;
+  a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
+  a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
+  a.ntaps = kh * kw; a.flags = flags;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
+  return sg_launch_igemm_bf16v2(a, (hipStream_t)stream, nullptr, 4);
 }
 
 // ==========================================================================================================
@@ -855,6 +1016,24 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
       }
     }
   };
+  // the MFMAs of a step with the four DMA parts of the next load tile (stage `st`) between the MFMA groups: the whole tile is
+  // issued one tile ahead of its use (see SG2_K_TILE)
+  auto mma_dma = [&](int slot, int st) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const v4i a4 = {af[slot][i][0][0], af[slot][i][0][1], af[slot][i][1][0], af[slot][i][1][1]};
+      const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a4), rfloor8));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const v4i b4 = {bfr[slot][j][0][0], bfr[slot][j][0][1], bfr[slot][j][1][0], bfr[slot][j][1][1]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b4), acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = i * 4 / TM; q < (i + 1) * 4 / TM; ++q) issue_part(st, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // wait until only the NF transposed reads just issued are still in flight
 #define SGW_WAIT_FRAGS()                                                                \
   do {                                                                                  \
@@ -869,20 +1048,18 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
     for (int i = 0; i < 4; ++i) issue_part(0, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue_part(1, 0);
-    issue_part(1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(1, i);
     SGW_READ_FRAGS(0, 0, 0);
   }
   // four k-steps per tile (one k-group)
 #define SGW_K_TILE4(st, sn)                                        \
   do {                                                             \
     SGW_READ_FRAGS(st, 1, 1);                                      \
-    issue_part(sn, 2);                                             \
     SGW_WAIT_FRAGS();                                              \
     mma(0);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
     SGW_READ_FRAGS(st, 2, 0);                                      \
-    issue_part(sn, 3);                                             \
     SGW_WAIT_FRAGS();                                              \
     mma(1);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
@@ -892,29 +1069,23 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
     __builtin_amdgcn_sched_barrier(0);                             \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_s_barrier();                                  \
-    issue_part(st, 0);                                             \
-    issue_part(st, 1);                                             \
     SGW_READ_FRAGS(sn, 0, 0);                                      \
     __builtin_amdgcn_sched_barrier(0);                             \
-    mma(1);                                                        \
+    mma_dma(1, st);                                                \
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
   // two k-steps per tile and wave (two k-groups)
 #define SGW_K_TILE2(st, sn)                                        \
   do {                                                             \
     SGW_READ_FRAGS(st, 1, 1);                                      \
-    issue_part(sn, 2);                                             \
-    issue_part(sn, 3);                                             \
     SGW_WAIT_FRAGS();                                              \
     mma(0);                                                        \
     __builtin_amdgcn_sched_barrier(0);                             \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_s_barrier();                                  \
-    issue_part(st, 0);                                             \
-    issue_part(st, 1);                                             \
     SGW_READ_FRAGS(sn, 0, 0);                                      \
     __builtin_amdgcn_sched_barrier(0);                             \
-    mma(1);                                                        \
+    mma_dma(1, st);                                                \
     __builtin_amdgcn_sched_barrier(0);                             \
   } while (0)
   for (int kt = 0; kt < KT; kt += 2) {
@@ -1136,4 +1307,301 @@ extern "C" int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, con
   long done = 0;
   const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 1);
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
+}
+
+// ==========================================================================================================
+// fp32 weight gradient, second generation:  dW_t[c][n] += sum_m s_b(m) P[pix(m) + tap_t][c] * Q[m][n]  (+ bias gradient)
+// Same decomposition as sg_wgrad_bf16v2_kernel<256, 256> with fp32 operands on v_mfma_f32_32x32x2_f32.  The MFMA takes ONE
+// float per lane and operand -- A[i = channel (l & 31)][k = pixel (l >> 5)] -- so a fragment is a plain ds_read_b32 of 32
+// consecutive channels of one pixel: the tiles ([32 pixels][256 channels], 1 KB per pixel) are DMA'd exactly as they lie
+// in memory (one wave instruction = one pixel row), no swizzle, no transpose, conflict-free.  16 k-steps of 2 pixels per
+// tile, 6 reads per 8 MFMAs (512 matrix cycles): matrix-pipe bound.  The per-sample factors of the shared backward sweep
+// multiply the Q fragments in registers (a tile of 32 consecutive pixels spans at most two samples: two scalars per tile);
+// the tap-0 / c-tile-0 workgroups also sum their Q fragments into the bias gradient.
+struct SgWgrad4Args {
+  const float* p;      // [Bn, H, W, Cp]
+  const float* q;      // [Bn, H, W, Cq]
+  float* dw;
+  float* dbias;        // nullable: [Cq] += column sums of (scaled) q
+  const float* qscale; // nullable: [Bn]
+  int Bn, H, W, Cp, Cq;
+  int ntaps, flags;    // SG_RELU_IN applies to P
+  int mchunk;          // pixels per workgroup (multiple of 32)
+  int c_tiles, n_tiles, nchunks;
+  SgTap taps[SG_MAX_TAPS];
+};
+
+__device__ float sg2_one_page[64] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                     1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                     1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+
+__global__ __launch_bounds__(512, 2) void sg_wgrad_v2_kernel(const SgWgrad4Args p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int PT = 32 * 256 * 4;                    // bytes of one operand tile (32 KB)
+  constexpr int SC0 = 4 * PT;                         // per-pixel factors: [stage][wave][64 floats] behind the operand tiles
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;                            // (kept in a VGPR: the cursor selects below must not become branches)
+  const int wave = __builtin_amdgcn_readfirstlane(wv);
+  const int wm = wave >> 2, wn = wave & 3;            // 2 (c) x 4 (n) waves, wave tile 128 x 64
+  const long M = (long)p.Bn * p.H * p.W;
+  const int combos = p.ntaps * p.c_tiles * p.n_tiles;
+  const int chunk = blockIdx.x / combos;
+  int combo = blockIdx.x - chunk * combos;
+  const int tap = combo / (p.c_tiles * p.n_tiles);
+  combo -= tap * p.c_tiles * p.n_tiles;
+  const int c0 = (combo / p.n_tiles) * 256, n0 = (combo % p.n_tiles) * 256;
+  const long m_begin = (long)chunk * p.mchunk;
+  const long m_end = m_begin + p.mchunk < M ? m_begin + p.mchunk : M;
+  const int m_len = (int)(m_end - m_begin);
+  const int KT = (m_len + 31) / 32;
+  const int tdy = p.taps[tap].dy, tdx = p.taps[tap].dx;
+  const int HW = p.H * p.W, Hh = p.H, Ww = p.W;
+  const bool do_bias = p.dbias != nullptr && tap == 0 && c0 == 0 && wm == 0;
+
+  // ---- DMA: instruction i (0..3) of wave w moves pixel row 8 i + w of the tile, lane -> channels 4 l .. + 3
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(sg2_zero_page) + 16 * (lane & 15);
+  int rrow = wv;                   // pixel row (relative to m_begin) of instruction 0 in the CURRENT load tile; instruction i: + 8 i
+  int ry[4], rx[4];
+  {
+    const int rem0 = (int)(m_begin % HW);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int rem = rem0 + 8 * i + wv;                    // < 2 HW (HW >= 32)
+      rem -= rem >= HW ? HW : 0;
+      ry[i] = rem / Ww;
+      rx[i] = rem - ry[i] * Ww;
+    }
+  }
+  const int adv_y = (32 % HW) / Ww, adv_x = (32 % HW) % Ww;
+  const int tap_shift = tdy * Ww + tdx;
+  const unsigned rowp = (unsigned)p.Cp * 4u, rowq = (unsigned)p.Cq * 4u;
+  // addresses of instruction 0's row in the CURRENT load tile (P: already shifted by the tap); instruction i: + 8 i rows
+  unsigned long long pcur = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 4ull * (unsigned)(c0 + 4 * lane) +
+                            (unsigned long long)((m_begin + wv + tap_shift) * (long)rowp);
+  unsigned long long qcur = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 4ull * (unsigned)(n0 + 4 * lane) +
+                            (unsigned long long)((m_begin + wv) * (long)rowq);
+  const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
+  const unsigned zlo = (unsigned)z_base64, zhi = (unsigned)(z_base64 >> 32);
+  auto issue_part = [&](int st, int i) {
+    const int live = (rrow + 8 * i) < m_len;
+    const int sy = ry[i] + tdy, sx = rx[i] + tdx;
+    const int okp = live & ((unsigned)sy < (unsigned)Hh) & ((unsigned)sx < (unsigned)Ww);
+    const unsigned long long pa = pcur + (unsigned long long)(8u * (unsigned)i * rowp);
+    const unsigned long long qa = qcur + (unsigned long long)(8u * (unsigned)i * rowq);
+    const unsigned plo = okp ? (unsigned)pa : zlo, phi = okp ? (unsigned)(pa >> 32) : zhi;
+    const unsigned qlo = live ? (unsigned)qa : zlo, qhi = live ? (unsigned)(qa >> 32) : zhi;
+    unsigned char* dst_p = smem + st * PT + (8 * i + wave) * 1024;
+    unsigned char* dst_q = dst_p + 2 * PT;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(((unsigned long long)phi << 32) | plo),
+                                     (__attribute__((address_space(3))) void*)dst_p, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(((unsigned long long)qhi << 32) | qlo),
+                                     (__attribute__((address_space(3))) void*)dst_q, 16, 0, 0);
+    rx[i] += adv_x;
+    const int wx = rx[i] >= Ww ? 1 : 0;
+    rx[i] -= wx * Ww;
+    ry[i] += adv_y + wx;
+    ry[i] -= ry[i] >= Hh ? Hh : 0;
+  };
+  auto next_tile = [&]() {
+    rrow += 32;
+    pcur += 32ull * rowp;
+    qcur += 32ull * rowq;
+  };
+  // per-pixel factors of the tile: lane l (< 32) of EVERY wave copies qscale[sample of pixel l] into the wave's own strip
+  // (no cross-wave dependence, no branch); without factors the source is a page of ones
+  int sb, srem;                     // sample index and in-plane offset of pixel (lane & 31) of the CURRENT load tile
+  {
+    const long m = m_begin + (lane & 31);
+    sb = (int)(m / HW);
+    srem = (int)(m - (long)sb * HW);
+  }
+  const int sadv_b = 32 / HW, sadv_r = 32 % HW;
+  const unsigned long long s_base64 = p.qscale ? (unsigned long long)reinterpret_cast<uintptr_t>(p.qscale) : (unsigned long long)reinterpret_cast<uintptr_t>(sg2_one_page);
+  const int s_mask = p.qscale ? -1 : 0;
+  const int b_last = p.Bn - 1;
+  auto issue_scales = [&](int st) {
+    const int bb = (sb < b_last ? sb : b_last) & s_mask;
+    const unsigned long long sa = s_base64 + 4ull * (unsigned)bb;
+    unsigned char* dst = smem + SC0 + st * 2048 + wave * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)sa, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+    srem += sadv_r;
+    const int c = srem >= HW ? 1 : 0;
+    srem -= c * HW;
+    sb += sadv_b + c;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment reads: lane (c or n = l & 31, pixel half h = l >> 5); k-step kk covers pixels 2 kk, 2 kk + 1
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int h = lane >> 5;
+  const unsigned pa_addr = lds0 + (unsigned)(h * 1024 + 4 * (wm * 128 + (lane & 31)));
+  const unsigned qb_addr = lds0 + (unsigned)(2 * PT + h * 1024 + 4 * (wn * 64 + (lane & 31)));
+  const unsigned sc_addr = lds0 + (unsigned)(SC0 + wave * 256 + 4 * h);
+  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
+  const int ifloor = relu_in ? 0 : (int)0x80000000;      // max as int32 against +0 = ReLU; against INT_MIN = identity
+  float af[2][4], bfr[2][2], scf[2];
+#define SGF_DSR(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define SGF_READ_FRAGS(st, kk, slot)                                       \
+  do {                                                                     \
+    SGF_DSR(scf[slot], sc_addr, (st) * 2048 + (kk) * 8);                   \
+    SGF_DSR(bfr[slot][0], qb_addr, (st) * PT + (kk) * 2048 + 0);           \
+    SGF_DSR(bfr[slot][1], qb_addr, (st) * PT + (kk) * 2048 + 128);         \
+    SGF_DSR(af[slot][0], pa_addr, (st) * PT + (kk) * 2048 + 0);            \
+    SGF_DSR(af[slot][1], pa_addr, (st) * PT + (kk) * 2048 + 128);          \
+    SGF_DSR(af[slot][2], pa_addr, (st) * PT + (kk) * 2048 + 256);          \
+    SGF_DSR(af[slot][3], pa_addr, (st) * PT + (kk) * 2048 + 384);          \
+  } while (0)
+  // VALU work in front of the MFMAs is not free on the fp32 stream (tools/mfma_peak.hip): one packed multiply for the two
+  // factors, one packed add for the bias sums, one v_max_i32 per A fragment (ReLU on the bit pattern: no canonicalising pre-pass)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f bsum2 = {0.f, 0.f};
+  auto mma = [&](int slot) {
+    const v2f b2 = v2f{bfr[slot][0], bfr[slot][1]} * v2f{scf[slot], scf[slot]};
+    bsum2 += b2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, af[slot][i]), ifloor));   // ONE v_max_i32
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[0], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[1], acc[i][1], 0, 0, 0);
+    }
+  };
+#define SGF_WAIT() do { asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SGF_STEP(st, kk_next, slot_next, slot_cur)  \
+  do {                                               \
+    SGF_READ_FRAGS(st, kk_next, slot_next);          \
+    SGF_WAIT();                                      \
+    mma(slot_cur);                                   \
+    __builtin_amdgcn_sched_barrier(0);               \
+  } while (0)
+
+  {
+    issue_scales(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(0, i);
+    next_tile();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_scales(1);
+    issue_part(1, 0);
+    issue_part(1, 1);
+    SGF_READ_FRAGS(0, 0, 0);
+  }
+  // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, factors + parts 0-1 of tile t+1 issued
+#define SGF_K_TILE(st, sn)                                         \
+  do {                                                             \
+    SGF_READ_FRAGS(st, 1, 1);                                      \
+    issue_part(sn, 2);                                             \
+    SGF_WAIT();                                                    \
+    mma(0);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    SGF_READ_FRAGS(st, 2, 0);                                      \
+    issue_part(sn, 3);                                             \
+    next_tile();                                                   \
+    SGF_WAIT();                                                    \
+    mma(1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    SGF_STEP(st, 3, 1, 0);                                         \
+    SGF_STEP(st, 4, 0, 1);                                         \
+    SGF_STEP(st, 5, 1, 0);                                         \
+    SGF_STEP(st, 6, 0, 1);                                         \
+    SGF_STEP(st, 7, 1, 0);                                         \
+    SGF_STEP(st, 8, 0, 1);                                         \
+    SGF_STEP(st, 9, 1, 0);                                         \
+    SGF_STEP(st, 10, 0, 1);                                        \
+    SGF_STEP(st, 11, 1, 0);                                        \
+    SGF_STEP(st, 12, 0, 1);                                        \
+    SGF_STEP(st, 13, 1, 0);                                        \
+    SGF_STEP(st, 14, 0, 1);                                        \
+    SGF_STEP(st, 15, 1, 0);                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                                  \
+    issue_scales(st);                                              \
+    issue_part(st, 0);                                             \
+    issue_part(st, 1);                                             \
+    SGF_READ_FRAGS(sn, 0, 0);                                      \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    mma(1);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+  for (int kt = 0; kt < KT; kt += 2) {
+    SGF_K_TILE(0, 1);
+    SGF_K_TILE(1, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  float* dwt = p.dw + p.taps[tap].w_off;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicAdd(dwt + (size_t)c * p.Cq + n, acc[i][j][r]);
+      }
+    }
+    if (do_bias) {
+      const float t = bsum2[j] + __shfl_xor(bsum2[j], 32, 64);     // the two pixel halves of the wave
+      if (h == 0) atomicAdd(p.dbias + n, t);
+    }
+  }
+}
+
+// Contract of sg_conv2d_bwd_weight (fp32 operands, dw += , dbias += , per-sample factors); SAME stride-1 convolutions (or 1x1)
+// with Cin % 256 == 0, Cout % 256 == 0 and H*W >= 32, else SG_ERR_UNSUPPORTED (caller: sg_conv2d_bwd_weight).
+extern "C" int sg_conv2d_bwd_weight_v2(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale, int B, int H,
+                                       int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+  if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (!pad_same && (kh != 1 || kw != 1)) return SG_ERR_UNSUPPORTED;
+  if ((Cin % 256) || (Cout % 256) || H * W < 32) return SG_ERR_UNSUPPORTED;
+  const long M = (long)B * H * W;
+  if (M <= 0) return SG_OK;
+  SgWgrad4Args a{};
+  a.p = x; a.q = dy; a.dw = dw; a.dbias = dbias; a.qscale = sample_scale;
+  a.Bn = B; a.H = H; a.W = W; a.Cp = Cin; a.Cq = Cout; a.ntaps = kh * kw; a.flags = flags;
+  const int ph = kh / 2, pw = kw / 2;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
+  a.c_tiles = Cin / 256;
+  a.n_tiles = Cout / 256;
+  const int combos = a.ntaps * a.c_tiles * a.n_tiles;
+  // chunk model of sg2_launch_wgrad: a 32-pixel fp32 k-tile takes 128 MFMAs of 64 cycles per wave, two waves per SIMD
+  // (~7 us), the epilogue's 256 KB of float atomics ~50 us per round
+  static const int wg_env = getenv("SG_WGRAD2_CHUNKS") ? atoi(getenv("SG_WGRAD2_CHUNKS")) : 0;
+  const long tiles_all = (M + 31) / 32;
+  const long max_chunks = tiles_all / 4 > 0 ? tiles_all / 4 : 1;
+  long nchunks = 1;
+  double best = 1e30;
+  for (long cc = 1; cc <= max_chunks && cc * combos <= 8192; ++cc) {
+    const long Wg = combos * cc;
+    const double t = (double)((Wg + 255) / 256) * ((double)((tiles_all + cc - 1) / cc) * 7.0 + 50.0);
+    if (t < best) { best = t; nchunks = cc; }
+  }
+  if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
+  long mchunk = (M + nchunks - 1) / nchunks;
+  mchunk = (mchunk + 31) / 32 * 32;
+  nchunks = (M + mchunk - 1) / mchunk;
+  a.mchunk = (int)mchunk;
+  a.nchunks = (int)nchunks;
+  constexpr int LDS_BYTES = 4 * 32 * 256 * 4 + 2 * 2048;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return SG_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sg_wgrad_v2_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  return sg_launch_status();
 }

@@ -238,9 +238,9 @@ def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
     kh, kw, Cin, Cout = w.shape
-    out = None if kind == "bwd_f32" else torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
-    if kind == "bwd_f32":            # fp32 [kh,kw,Cout,Cin]: the data-grad launch then reads it like a forward filter
-        out = torch.empty(kh, kw, Cout, Cin, device=w.device, dtype=torch.float32)
+    out = None if kind in ("bwd_f32", "fwd_f32t") else torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+    if kind in ("bwd_f32", "fwd_f32t"):   # fp32 [kh,kw,Cout,Cin]: per tap [N = Cout][K = Cin] for the second-generation forward
+        out = torch.empty(kh, kw, Cout, Cin, device=w.device, dtype=torch.float32)   # launch (and the old transposed data-grad option)
         call("sg_transpose_filter", _p(w), _p(out), kh * kw, Cin, Cout, _stream())
     elif kind == "t_fwd":            # Conv2DTranspose filter w [kh,kw,Co,Ci]: each tap already is [N = Co][K = Ci] -> convert only
         call("sg_pack_filter_bf16", _p(w), out.data_ptr(), kh * kw, w.shape[3], w.shape[2], 0, _stream())
@@ -326,6 +326,14 @@ def bf16_of(t: torch.Tensor) -> torch.Tensor:
     return t16
 
 
+USE_F32_V2 = _os.environ.get("SG_F32_V2", "1") == "1"
+
+
+def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
+    """fp32 mode: the DMA-fed second-generation kernel takes the stride-1 convs whose channel counts sit on its tile grid."""
+    return USE_F32_V2 and CONV_DTYPE == "f32" and K % 32 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
+
+
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
     return USE_V2 and _low() and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
 
@@ -358,6 +366,9 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
                  None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
             if y16 is not None:
                 _twin_put(out, y16)
+        elif _f32v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+            call("sg_conv2d_fwd_v2", _p(x), _p(packed_filter(w, "fwd_f32t")), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw,
+                 int(same), _flags(relu_in, accum, relu_out), _stream())
         elif _bf16_ok(Cin, Cout) and not tanh_out:
             call("sg_conv2d_fwd_bf16", _p(x), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout,
                  kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
@@ -397,6 +408,8 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
                  None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
             if dx16 is not None:
                 _twin_put(out, dx16)
+        elif _f32v2_ok(Cout, Cin, kh, kw, same):
+            call("sg_conv2d_bwd_data_v2", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
         elif _bf16_ok(Cout, Cin):
             call("sg_conv2d_bwd_data_bf16", _p(dy), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out), B, H, W, Cin, Cout,
                  kh, kw, int(same), _flags(accum=accum), _stream())
@@ -427,6 +440,12 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
                  _flags(relu_in), _stream())
         if db is not None:
             bias_grad(dy if sample_scale is None else rowscale(dy, sample_scale), db)
+        return
+    if USE_F32_V2 and not _low() and (same or kh * kw == 1) and Cin % 256 == 0 and Cout % 256 == 0 and H * W >= 32:
+        # second-generation fp32 path: operand tiles by DMA as they lie in memory, factors and bias gradient in the same sweep
+        with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
+            call("sg_conv2d_bwd_weight_v2", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
+                 _flags(relu_in), _stream())
         return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):

@@ -46,6 +46,8 @@ CONV_CASES = [
     (2, 8, 8, 1, 64, 1, True),        # thin 1x1 shortcut
     (2, 8, 8, 64, 1, 3, True),        # thin contract (generator head)
     (5, 7, 5, 16, 32, 3, True),       # odd spatial dims, M not a multiple of anything
+    (3, 4, 9, 256, 256, 3, True),     # DMA-fed fp32 weight-grad tiles: ragged last pixel tile, sample boundary inside a tile
+    (2, 5, 7, 256, 512, 1, True),     # ... 1x1, two Cout tiles
 ]
 
 

@@ -73,11 +73,6 @@ int sg_conv2d_fwd_v2(const float* x, const float* wt_fwd, const float* bias, con
 int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, float* dx,
                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
-/* fp32 weight gradient, second generation (same contract as sg_conv2d_bwd_weight: dw += , dbias += , optional per-sample
- * factors); stride-1 SAME (or 1x1) convolutions with Cin % 256 == 0, Cout % 256 == 0 and H*W >= 32, else SG_ERR_UNSUPPORTED. */
-int sg_conv2d_bwd_weight_v2(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale, int B, int H, int W,
-                            int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
-
 /* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
  *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale
  *      (nullable, [n / rowlen], rowlen % 8 == 0) multiplies row r by rowscale[r] first (the per-sample factors of the shared

@@ -1308,300 +1308,3 @@ extern "C" int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, con
   const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 1);
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
 }
-
-// ==========================================================================================================
-// fp32 weight gradient, second generation:  dW_t[c][n] += sum_m s_b(m) P[pix(m) + tap_t][c] * Q[m][n]  (+ bias gradient)
-// Same decomposition as sg_wgrad_bf16v2_kernel<256, 256> with fp32 operands on v_mfma_f32_32x32x2_f32.  The MFMA takes ONE
-// float per lane and operand -- A[i = channel (l & 31)][k = pixel (l >> 5)] -- so a fragment is a plain ds_read_b32 of 32
-// consecutive channels of one pixel: the tiles ([32 pixels][256 channels], 1 KB per pixel) are DMA'd exactly as they lie
-// in memory (one wave instruction = one pixel row), no swizzle, no transpose, conflict-free.  16 k-steps of 2 pixels per
-// tile, 6 reads per 8 MFMAs (512 matrix cycles): matrix-pipe bound.  The per-sample factors of the shared backward sweep
-// multiply the Q fragments in registers (a tile of 32 consecutive pixels spans at most two samples: two scalars per tile);
-// the tap-0 / c-tile-0 workgroups also sum their Q fragments into the bias gradient.
-struct SgWgrad4Args {
-  const float* p;      // [Bn, H, W, Cp]
-  const float* q;      // [Bn, H, W, Cq]
-  float* dw;
-  float* dbias;        // nullable: [Cq] += column sums of (scaled) q
-  const float* qscale; // nullable: [Bn]
-  int Bn, H, W, Cp, Cq;
-  int ntaps, flags;    // SG_RELU_IN applies to P
-  int mchunk;          // pixels per workgroup (multiple of 32)
-  int c_tiles, n_tiles, nchunks;
-  SgTap taps[SG_MAX_TAPS];
-};
-
-__device__ float sg2_one_page[64] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
-                                     1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
-                                     1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-
-__global__ __launch_bounds__(512, 2) void sg_wgrad_v2_kernel(const SgWgrad4Args p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int PT = 32 * 256 * 4;                    // bytes of one operand tile (32 KB)
-  constexpr int SC0 = 4 * PT;                         // per-pixel factors: [stage][wave][64 floats] behind the operand tiles
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = tid >> 6;                            // (kept in a VGPR: the cursor selects below must not become branches)
-  const int wave = __builtin_amdgcn_readfirstlane(wv);
-  const int wm = wave >> 2, wn = wave & 3;            // 2 (c) x 4 (n) waves, wave tile 128 x 64
-  const long M = (long)p.Bn * p.H * p.W;
-  const int combos = p.ntaps * p.c_tiles * p.n_tiles;
-  const int chunk = blockIdx.x / combos;
-  int combo = blockIdx.x - chunk * combos;
-  const int tap = combo / (p.c_tiles * p.n_tiles);
-  combo -= tap * p.c_tiles * p.n_tiles;
-  const int c0 = (combo / p.n_tiles) * 256, n0 = (combo % p.n_tiles) * 256;
-  const long m_begin = (long)chunk * p.mchunk;
-  const long m_end = m_begin + p.mchunk < M ? m_begin + p.mchunk : M;
-  const int m_len = (int)(m_end - m_begin);
-  const int KT = (m_len + 31) / 32;
-  const int tdy = p.taps[tap].dy, tdx = p.taps[tap].dx;
-  const int HW = p.H * p.W, Hh = p.H, Ww = p.W;
-  const bool do_bias = p.dbias != nullptr && tap == 0 && c0 == 0 && wm == 0;
-
-  // ---- DMA: instruction i (0..3) of wave w moves pixel row 8 i + w of the tile, lane -> channels 4 l .. + 3
-  const unsigned char* zero = reinterpret_cast<const unsigned char*>(sg2_zero_page) + 16 * (lane & 15);
-  int rrow = wv;                   // pixel row (relative to m_begin) of instruction 0 in the CURRENT load tile; instruction i: + 8 i
-  int ry[4], rx[4];
-  {
-    const int rem0 = (int)(m_begin % HW);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int rem = rem0 + 8 * i + wv;                    // < 2 HW (HW >= 32)
-      rem -= rem >= HW ? HW : 0;
-      ry[i] = rem / Ww;
-      rx[i] = rem - ry[i] * Ww;
-    }
-  }
-  const int adv_y = (32 % HW) / Ww, adv_x = (32 % HW) % Ww;
-  const int tap_shift = tdy * Ww + tdx;
-  const unsigned rowp = (unsigned)p.Cp * 4u, rowq = (unsigned)p.Cq * 4u;
-  // addresses of instruction 0's row in the CURRENT load tile (P: already shifted by the tap); instruction i: + 8 i rows
-  unsigned long long pcur = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 4ull * (unsigned)(c0 + 4 * lane) +
-                            (unsigned long long)((m_begin + wv + tap_shift) * (long)rowp);
-  unsigned long long qcur = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 4ull * (unsigned)(n0 + 4 * lane) +
-                            (unsigned long long)((m_begin + wv) * (long)rowq);
-  const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
-  const unsigned zlo = (unsigned)z_base64, zhi = (unsigned)(z_base64 >> 32);
-  auto issue_part = [&](int st, int i) {
-    const int live = (rrow + 8 * i) < m_len;
-    const int sy = ry[i] + tdy, sx = rx[i] + tdx;
-    const int okp = live & ((unsigned)sy < (unsigned)Hh) & ((unsigned)sx < (unsigned)Ww);
-    const unsigned long long pa = pcur + (unsigned long long)(8u * (unsigned)i * rowp);
-    const unsigned long long qa = qcur + (unsigned long long)(8u * (unsigned)i * rowq);
-    const unsigned plo = okp ? (unsigned)pa : zlo, phi = okp ? (unsigned)(pa >> 32) : zhi;
-    const unsigned qlo = live ? (unsigned)qa : zlo, qhi = live ? (unsigned)(qa >> 32) : zhi;
-    unsigned char* dst_p = smem + st * PT + (8 * i + wave) * 1024;
-    unsigned char* dst_q = dst_p + 2 * PT;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(((unsigned long long)phi << 32) | plo),
-                                     (__attribute__((address_space(3))) void*)dst_p, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)(((unsigned long long)qhi << 32) | qlo),
-                                     (__attribute__((address_space(3))) void*)dst_q, 16, 0, 0);
-    rx[i] += adv_x;
-    const int wx = rx[i] >= Ww ? 1 : 0;
-    rx[i] -= wx * Ww;
-    ry[i] += adv_y + wx;
-    ry[i] -= ry[i] >= Hh ? Hh : 0;
-  };
-  auto next_tile = [&]() {
-    rrow += 32;
-    pcur += 32ull * rowp;
-    qcur += 32ull * rowq;
-  };
-  // per-pixel factors of the tile: lane l (< 32) of EVERY wave copies qscale[sample of pixel l] into the wave's own strip
-  // (no cross-wave dependence, no branch); without factors the source is a page of ones
-  int sb, srem;                     // sample index and in-plane offset of pixel (lane & 31) of the CURRENT load tile
-  {
-    const long m = m_begin + (lane & 31);
-    sb = (int)(m / HW);
-    srem = (int)(m - (long)sb * HW);
-  }
-  const int sadv_b = 32 / HW, sadv_r = 32 % HW;
-  const unsigned long long s_base64 = p.qscale ? (unsigned long long)reinterpret_cast<uintptr_t>(p.qscale) : (unsigned long long)reinterpret_cast<uintptr_t>(sg2_one_page);
-  const int s_mask = p.qscale ? -1 : 0;
-  const int b_last = p.Bn - 1;
-  auto issue_scales = [&](int st) {
-    const int bb = (sb < b_last ? sb : b_last) & s_mask;
-    const unsigned long long sa = s_base64 + 4ull * (unsigned)bb;
-    unsigned char* dst = smem + SC0 + st * 2048 + wave * 256;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)sa, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
-    srem += sadv_r;
-    const int c = srem >= HW ? 1 : 0;
-    srem -= c * HW;
-    sb += sadv_b + c;
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- fragment reads: lane (c or n = l & 31, pixel half h = l >> 5); k-step kk covers pixels 2 kk, 2 kk + 1
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int h = lane >> 5;
-  const unsigned pa_addr = lds0 + (unsigned)(h * 1024 + 4 * (wm * 128 + (lane & 31)));
-  const unsigned qb_addr = lds0 + (unsigned)(2 * PT + h * 1024 + 4 * (wn * 64 + (lane & 31)));
-  const unsigned sc_addr = lds0 + (unsigned)(SC0 + wave * 256 + 4 * h);
-  const bool relu_in = (p.flags & SG_RELU_IN) != 0;
-  const int ifloor = relu_in ? 0 : (int)0x80000000;      // max as int32 against +0 = ReLU; against INT_MIN = identity
-  float af[2][4], bfr[2][2], scf[2];
-#define SGF_DSR(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define SGF_READ_FRAGS(st, kk, slot)                                       \
-  do {                                                                     \
-    SGF_DSR(scf[slot], sc_addr, (st) * 2048 + (kk) * 8);                   \
-    SGF_DSR(bfr[slot][0], qb_addr, (st) * PT + (kk) * 2048 + 0);           \
-    SGF_DSR(bfr[slot][1], qb_addr, (st) * PT + (kk) * 2048 + 128);         \
-    SGF_DSR(af[slot][0], pa_addr, (st) * PT + (kk) * 2048 + 0);            \
-    SGF_DSR(af[slot][1], pa_addr, (st) * PT + (kk) * 2048 + 128);          \
-    SGF_DSR(af[slot][2], pa_addr, (st) * PT + (kk) * 2048 + 256);          \
-    SGF_DSR(af[slot][3], pa_addr, (st) * PT + (kk) * 2048 + 384);          \
-  } while (0)
-  // VALU work in front of the MFMAs is not free on the fp32 stream (tools/mfma_peak.hip): one packed multiply for the two
-  // factors, one packed add for the bias sums, one v_max_i32 per A fragment (ReLU on the bit pattern: no canonicalising pre-pass)
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  v2f bsum2 = {0.f, 0.f};
-  auto mma = [&](int slot) {
-    const v2f b2 = v2f{bfr[slot][0], bfr[slot][1]} * v2f{scf[slot], scf[slot]};
-    bsum2 += b2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, af[slot][i]), ifloor));   // ONE v_max_i32
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[0], acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[1], acc[i][1], 0, 0, 0);
-    }
-  };
-#define SGF_WAIT() do { asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define SGF_STEP(st, kk_next, slot_next, slot_cur)  \
-  do {                                               \
-    SGF_READ_FRAGS(st, kk_next, slot_next);          \
-    SGF_WAIT();                                      \
-    mma(slot_cur);                                   \
-    __builtin_amdgcn_sched_barrier(0);               \
-  } while (0)
-
-  {
-    issue_scales(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_part(0, i);
-    next_tile();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_scales(1);
-    issue_part(1, 0);
-    issue_part(1, 1);
-    SGF_READ_FRAGS(0, 0, 0);
-  }
-  // tile t in stage t & 1; on entry: fragments of (t, step 0) in flight into slot 0, factors + parts 0-1 of tile t+1 issued
-#define SGF_K_TILE(st, sn)                                         \
-  do {                                                             \
-    SGF_READ_FRAGS(st, 1, 1);                                      \
-    issue_part(sn, 2);                                             \
-    SGF_WAIT();                                                    \
-    mma(0);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    SGF_READ_FRAGS(st, 2, 0);                                      \
-    issue_part(sn, 3);                                             \
-    next_tile();                                                   \
-    SGF_WAIT();                                                    \
-    mma(1);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    SGF_STEP(st, 3, 1, 0);                                         \
-    SGF_STEP(st, 4, 0, 1);                                         \
-    SGF_STEP(st, 5, 1, 0);                                         \
-    SGF_STEP(st, 6, 0, 1);                                         \
-    SGF_STEP(st, 7, 1, 0);                                         \
-    SGF_STEP(st, 8, 0, 1);                                         \
-    SGF_STEP(st, 9, 1, 0);                                         \
-    SGF_STEP(st, 10, 0, 1);                                        \
-    SGF_STEP(st, 11, 1, 0);                                        \
-    SGF_STEP(st, 12, 0, 1);                                        \
-    SGF_STEP(st, 13, 1, 0);                                        \
-    SGF_STEP(st, 14, 0, 1);                                        \
-    SGF_STEP(st, 15, 1, 0);                                        \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
-    __builtin_amdgcn_s_barrier();                                  \
-    issue_scales(st);                                              \
-    issue_part(st, 0);                                             \
-    issue_part(st, 1);                                             \
-    SGF_READ_FRAGS(sn, 0, 0);                                      \
-    __builtin_amdgcn_sched_barrier(0);                             \
-    mma(1);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                             \
-  } while (0)
-  for (int kt = 0; kt < KT; kt += 2) {
-    SGF_K_TILE(0, 1);
-    SGF_K_TILE(1, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  float* dwt = p.dw + p.taps[tap].w_off;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = c0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        atomicAdd(dwt + (size_t)c * p.Cq + n, acc[i][j][r]);
-      }
-    }
-    if (do_bias) {
-      const float t = bsum2[j] + __shfl_xor(bsum2[j], 32, 64);     // the two pixel halves of the wave
-      if (h == 0) atomicAdd(p.dbias + n, t);
-    }
-  }
-}
-
-// Contract of sg_conv2d_bwd_weight (fp32 operands, dw += , dbias += , per-sample factors); SAME stride-1 convolutions (or 1x1)
-// with Cin % 256 == 0, Cout % 256 == 0 and H*W >= 32, else SG_ERR_UNSUPPORTED (caller: sg_conv2d_bwd_weight).
-extern "C" int sg_conv2d_bwd_weight_v2(const float* x, const float* dy, float* dw, float* dbias, const float* sample_scale, int B, int H,
-                                       int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
-  if (!x || !dy || !dw || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
-  if (!pad_same && (kh != 1 || kw != 1)) return SG_ERR_UNSUPPORTED;
-  if ((Cin % 256) || (Cout % 256) || H * W < 32) return SG_ERR_UNSUPPORTED;
-  const long M = (long)B * H * W;
-  if (M <= 0) return SG_OK;
-  SgWgrad4Args a{};
-  a.p = x; a.q = dy; a.dw = dw; a.dbias = dbias; a.qscale = sample_scale;
-  a.Bn = B; a.H = H; a.W = W; a.Cp = Cin; a.Cq = Cout; a.ntaps = kh * kw; a.flags = flags;
-  const int ph = kh / 2, pw = kw / 2;
-  for (int ky = 0; ky < kh; ++ky)
-    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
-  a.c_tiles = Cin / 256;
-  a.n_tiles = Cout / 256;
-  const int combos = a.ntaps * a.c_tiles * a.n_tiles;
-  // chunk model of sg2_launch_wgrad: a 32-pixel fp32 k-tile takes 128 MFMAs of 64 cycles per wave, two waves per SIMD
-  // (~7 us), the epilogue's 256 KB of float atomics ~50 us per round
-  static const int wg_env = getenv("SG_WGRAD2_CHUNKS") ? atoi(getenv("SG_WGRAD2_CHUNKS")) : 0;
-  const long tiles_all = (M + 31) / 32;
-  const long max_chunks = tiles_all / 4 > 0 ? tiles_all / 4 : 1;
-  long nchunks = 1;
-  double best = 1e30;
-  for (long cc = 1; cc <= max_chunks && cc * combos <= 8192; ++cc) {
-    const long Wg = combos * cc;
-    const double t = (double)((Wg + 255) / 256) * ((double)((tiles_all + cc - 1) / cc) * 7.0 + 50.0);
-    if (t < best) { best = t; nchunks = cc; }
-  }
-  if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
-  long mchunk = (M + nchunks - 1) / nchunks;
-  mchunk = (mchunk + 31) / 32 * 32;
-  nchunks = (M + mchunk - 1) / mchunk;
-  a.mchunk = (int)mchunk;
-  a.nchunks = (int)nchunks;
-  constexpr int LDS_BYTES = 4 * 32 * 256 * 4 + 2 * 2048;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      return SG_ERR_UNSUPPORTED;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(sg_wgrad_v2_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-  return sg_launch_status();
-}

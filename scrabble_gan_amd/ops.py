@@ -329,9 +329,18 @@ def bf16_of(t: torch.Tensor) -> torch.Tensor:
 USE_F32_V2 = _os.environ.get("SG_F32_V2", "1") == "1"
 
 
-def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
-    """fp32 mode: the DMA-fed second-generation kernel takes the stride-1 convs whose channel counts sit on its tile grid."""
-    return USE_F32_V2 and CONV_DTYPE == "f32" and K % 32 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
+F32_V2_MIN_TILES = 512      # (tests set 0: every eligible shape through the second-generation kernel)
+
+
+def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool, pixels: int) -> bool:
+    """fp32 mode: the DMA-fed second-generation kernel (256-pixel tiles, one workgroup per CU) takes the stride-1 convs on its
+    tile grid that fill at least two rounds of the 256 CUs and reduce over >= 1024 terms; measured per layer at bs 128
+    (profiles/r02_shapes_bs128.txt): +5..10 % on the data-grads (no ReLU in the loop), level on the forward convs, behind the
+    first-generation kernel (128 x 128 tiles, two workgroups per CU) on small grids and short reductions."""
+    if not (USE_F32_V2 and CONV_DTYPE == "f32" and K % 32 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))):
+        return False
+    tiles = -(-pixels // 256) * -(-N // 256)
+    return tiles >= F32_V2_MIN_TILES and (F32_V2_MIN_TILES == 0 or kh * kw * K >= 1024)
 
 
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
@@ -366,7 +375,7 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
                  None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
             if y16 is not None:
                 _twin_put(out, y16)
-        elif _f32v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+        elif _f32v2_ok(Cin, Cout, kh, kw, same, out.shape[0] * out.shape[1] * out.shape[2]) and not tanh_out:
             call("sg_conv2d_fwd_v2", _p(x), _p(packed_filter(w, "fwd_f32t")), _p(bias), _p(bias2), _p(out), B, H, W, Cin, Cout, kh, kw,
                  int(same), _flags(relu_in, accum, relu_out), _stream())
         elif _bf16_ok(Cin, Cout) and not tanh_out:
@@ -408,7 +417,7 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
                  None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
             if dx16 is not None:
                 _twin_put(out, dx16)
-        elif _f32v2_ok(Cout, Cin, kh, kw, same):
+        elif _f32v2_ok(Cout, Cin, kh, kw, same, B * H * W):
             call("sg_conv2d_bwd_data_v2", _p(dy), _p(w), _p(mask), _p(out), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
         elif _bf16_ok(Cout, Cin):
             call("sg_conv2d_bwd_data_bf16", _p(dy), packed_filter(w, "bwd").data_ptr(), _p(mask), _p(out), B, H, W, Cin, Cout,
@@ -440,12 +449,6 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
                  _flags(relu_in), _stream())
         if db is not None:
             bias_grad(dy if sample_scale is None else rowscale(dy, sample_scale), db)
-        return
-    if USE_F32_V2 and not _low() and (same or kh * kw == 1) and Cin % 256 == 0 and Cout % 256 == 0 and H * W >= 32:
-        # second-generation fp32 path: operand tiles by DMA as they lie in memory, factors and bias gradient in the same sweep
-        with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
-            call("sg_conv2d_bwd_weight_v2", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
-                 _flags(relu_in), _stream())
         return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):

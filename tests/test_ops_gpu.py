@@ -46,13 +46,24 @@ CONV_CASES = [
     (2, 8, 8, 1, 64, 1, True),        # thin 1x1 shortcut
     (2, 8, 8, 64, 1, 3, True),        # thin contract (generator head)
     (5, 7, 5, 16, 32, 3, True),       # odd spatial dims, M not a multiple of anything
-    (3, 4, 9, 256, 256, 3, True),     # DMA-fed fp32 weight-grad tiles: ragged last pixel tile, sample boundary inside a tile
+    (3, 4, 9, 256, 256, 3, True),     # 256-channel tiles: ragged last pixel tile, sample boundary inside a tile
     (2, 5, 7, 256, 512, 1, True),     # ... 1x1, two Cout tiles
 ]
 
 
+@pytest.fixture(params=["default-route", "f32-v2"])
+def f32_route(request):
+    """fp32 convs through the default routing (small shapes: first-generation kernels) and with every eligible shape forced
+    through the DMA-fed second-generation kernel (ops.F32_V2_MIN_TILES = 0)."""
+    from scrabble_gan_amd import ops
+    old = ops.F32_V2_MIN_TILES
+    ops.F32_V2_MIN_TILES = 0 if request.param == "f32-v2" else old
+    yield request.param
+    ops.F32_V2_MIN_TILES = old
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,same", CONV_CASES)
-def test_conv2d_fwd_bwd(dev, gen, B, H, W, Cin, Cout, k, same):
+def test_conv2d_fwd_bwd(dev, gen, f32_route, B, H, W, Cin, Cout, k, same):
     from scrabble_gan_amd import ops
     x = rnd(gen, B, H, W, Cin).requires_grad_(True)
     w = (rnd(gen, k, k, Cin, Cout) / math.sqrt(k * k * Cin)).requires_grad_(True)
@@ -105,7 +116,7 @@ def test_conv2d_bwd_data_transposed_filter_copy(dev, gen):
     close(ops.conv2d_bwd_data(g32(dy, dev), g32(w, dev), (H, W), mask=g32(x, dev)), ref, 5e-5, "dx")
 
 
-def test_conv2d_epilogues(dev, gen):
+def test_conv2d_epilogues(dev, gen, f32_route):
     from scrabble_gan_amd import ops
     B, H, W, Cin, Cout = 2, 8, 12, 64, 128
     x, w = rnd(gen, B, H, W, Cin), rnd(gen, 3, 3, Cin, Cout) / 24

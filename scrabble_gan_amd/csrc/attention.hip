@@ -1,380 +1,329 @@
 // NonLocalBlock core: softmax(theta . phi^T) . g without materialising the [Nq, Nk] map
-// (/root/reference/src/bigacgan/arch_ops.py:51-52,61; un-scaled dot product, d_k = C/8, d_v = C/2).
+// (/root/reference/src/bigacgan/arch_ops.py:51-52,61; un-scaled dot product, d_k = C/8 = 8, d_v = C/2 = 32).
 //
-// Head dims here are tiny (d_k = 8, d_v = 32): an MFMA tile would be >75 % padding, so this is a
-// VALU flash-style kernel.  One lane owns one query row (q, running max/sum and the 32-wide
-// accumulator live in registers); keys/values stream through LDS in tiles and are read as
-// wave-uniform broadcasts (no bank conflicts); the online-softmax rescale is amortised over
-// groups of 8 keys.  The backward pass recomputes p = exp(s - lse) in two sweeps:
-//   dq sweep  : lane = query, streams keys    -> dtheta, delta
-//   dkv sweep : lane = key,   streams queries -> dphi, dg      (no atomics, deterministic)
+// Flash-style kernels on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation -- twice
+// the rate of plain VALU FMAs, and no per-key LDS broadcast reads, which bound round 1's one-lane-per-query VALU kernels).
+// Everything is computed TRANSPOSED so that no intermediate ever changes its register layout:
+//   forward, lane = query:  S^T = K Q^T   (A = K block [key][d],  B = Q^T [d][q])      4 MFMAs per 32 keys x 32 queries
+//                           the accumulator holds S^T[key(u, h)][q = lane & 31], key(u, h) = (u & 3) + 8 (u >> 2) + 4 h:
+//                           the softmax statistics of a query are reductions over the lane's own 16 registers plus one
+//                           cross-half shuffle, the rescale of O^T is a per-lane scalar, and register u of P^T IS the B
+//                           operand of step u of   O^T += V^T P^T   (A = V^T [c][key pair u])             16 MFMAs
+//                           (the order of the reduction index is free as long as both operands agree)
+//   backward, two sweeps (as in round 1: no atomics, deterministic):
+//     dq sweep,  lane = query: S^T, P^T = exp(S^T - lse), dP^T = V dO^T (16), dS^T = P^T (dP^T - delta),
+//                              dQ^T += K^T dS^T (16; rows d >= 8 of the 32-row tile are padding)
+//     dkv sweep, lane = key:   S = Q K^T (4), P, dP = dO V^T (16), dS, dV^T += dO^T P (16), dK^T += Q^T dS (16, padded)
+// Tiles of the streamed operand (keys for the query sweeps, queries for the key sweep) are staged in LDS with odd row
+// strides (9 / 33 floats) so that both the row reads and the column reads of the MFMA operands are conflict-free or 2-way.
 #include "sg_common.h"
 
 #define AT_DK 8
 #define AT_DV 32
-#define AT_KT 128   // keys (or queries) per LDS tile
+#define AT_KT 128   // keys per LDS tile of the query sweeps
+#define AT_QT 64    // queries per LDS tile of the key sweep
+#define AT_KS 9     // LDS row stride of theta / phi rows (floats)
+#define AT_VS 33    // LDS row stride of g / dO rows where columns are read (dq, dkv sweeps)
+#define AT_VF 40    // ... where only rows are read (forward): 4 rows apart = 32 banks apart, conflict-free
 
-__global__ __launch_bounds__(256) void k_attn_fwd(const float* theta, const float* phi, const float* g, float* out, float* lse,
-                                                  int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) float ks[AT_KT * AT_DK];
-  __shared__ __attribute__((aligned(16))) float vs[AT_KT * AT_DV];
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int at_row(int u, int h) { return (u & 3) + 8 * (u >> 2) + 4 * h; }   // accumulator register -> tile row
+// exp(x) = 2^(x log2 e) on v_exp_f32, with the rounding error of the product (and of the constant) folded back in: the
+// plain product is off by up to |x| * 6e-8 in the exponent, i.e. 2e-6 relative at x = -50; this form stays within ~2 ulp
+__device__ __forceinline__ float at_exp(float x) {
+  const float t = x * 1.44269502162933349609375f;                                    // float(log2 e)
+  const float e = __builtin_fmaf(x, 1.44269502162933349609375f, -t) + x * 1.925963033500011e-8f;   // + x * (log2 e - float(log2 e))
+  const float p = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(p, e * 0.693147180559945309f, p);
+}
+__device__ __forceinline__ float at_xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: WAVES waves x QB blocks of 32 queries per workgroup
+template <int WAVES, int QB>
+__global__ __launch_bounds__(WAVES * 64) void k_attn_fwd(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                         const float* __restrict__ g, float* __restrict__ out, float* __restrict__ lse,
+                                                         int Nq, int Nk) {
+  __shared__ float ks[AT_KT * AT_KS];
+  __shared__ float vs[AT_KT * AT_VF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
   const int b = blockIdx.y;
-  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = qi < Nq;
-  float q[AT_DK];
+  const int q_base = (blockIdx.x * WAVES + wave) * (QB * 32);
+  float qf[QB][4], m[QB], l[QB];
+  f32x16 o[QB];
 #pragma unroll
-  for (int d = 0; d < AT_DK; ++d) q[d] = live ? theta[((size_t)b * Nq + qi) * AT_DK + d] : 0.f;
-  float m = -INFINITY, l = 0.f, acc[AT_DV];
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q_base + qb * 32 + c;
 #pragma unroll
-  for (int c = 0; c < AT_DV; ++c) acc[c] = 0.f;
-
+    for (int t = 0; t < 4; ++t) qf[qb][t] = q < Nq ? theta[((size_t)b * Nq + q) * AT_DK + 2 * t + h] : 0.f;
+    m[qb] = -INFINITY;
+    l[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[qb][r] = 0.f;
+  }
   for (int k0 = 0; k0 < Nk; k0 += AT_KT) {
     const int kn = min(AT_KT, Nk - k0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += blockDim.x)
-      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
-          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += blockDim.x)
-      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
-          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < AT_KT * AT_DK; e += WAVES * 64) {
+      const int key = e >> 3, d = e & 7;
+      ks[key * AT_KS + d] = key < kn ? phi[((size_t)b * Nk + k0 + key) * AT_DK + d] : 0.f;
+    }
+    for (int e = tid; e < AT_KT * AT_DV; e += WAVES * 64) {
+      const int key = e >> 5, cc = e & 31;
+      vs[key * AT_VF + cc] = key < kn ? g[((size_t)b * Nk + k0 + key) * AT_DV + cc] : 0.f;
+    }
     __syncthreads();
-    for (int j0 = 0; j0 < kn; j0 += 8) {
-      float s[8];
-      float mx = m;
+    const int nblk = (kn + 31) >> 5;
+    for (int kb = 0; kb < nblk; ++kb) {
+      float ka[4], va[16];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float4 ka = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2];
-        const float4 kb = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2 + 1];
-        float t = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
-        if (j0 + jj >= kn) t = -INFINITY;
-        s[jj] = t;
-        mx = fmaxf(mx, t);
-      }
-      const float sc = expf(m - mx);      // m = -inf on the first group -> 0
-      l *= sc;
+      for (int t = 0; t < 4; ++t) ka[t] = ks[(kb * 32 + c) * AT_KS + 2 * t + h];
 #pragma unroll
-      for (int c = 0; c < AT_DV; ++c) acc[c] *= sc;
-      m = mx;
+      for (int u = 0; u < 16; ++u) va[u] = vs[(kb * 32 + at_row(u, h)) * AT_VF + c];
+      const bool ragged = kb * 32 + 32 > kn;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float p = expf(s[jj] - m);
-        l += p;
-        const float4* vp = reinterpret_cast<const float4*>(vs + (j0 + jj) * AT_DV);
+      for (int qb = 0; qb < QB; ++qb) {
+        f32x16 s;
 #pragma unroll
-        for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-          const float4 v = vp[c4];
-          acc[4 * c4 + 0] += p * v.x; acc[4 * c4 + 1] += p * v.y; acc[4 * c4 + 2] += p * v.z; acc[4 * c4 + 3] += p * v.w;
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qf[qb][t], s, 0, 0, 0);
+        if (ragged) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (kb * 32 + at_row(u, h) >= kn) s[u] = -INFINITY;
         }
+        float mx = s[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) mx = fmaxf(mx, s[u]);
+        mx = fmaxf(mx, at_xor32(mx));
+        const float mn = fmaxf(m[qb], mx);          // finite: key kb * 32 of the block is always a real key
+        const float sc = at_exp(m[qb] - mn);        // m = -inf before the first block -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          s[u] = at_exp(s[u] - mn);
+          rs += s[u];
+        }
+        rs += at_xor32(rs);
+        l[qb] = l[qb] * sc + rs;
+        m[qb] = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qb][r] *= sc;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) o[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[u], s[u], o[qb], 0, 0, 0);
       }
     }
   }
-  if (live) {
-    const float inv = 1.f / l;
-    float4* op = reinterpret_cast<float4*>(out + ((size_t)b * Nq + qi) * AT_DV);
 #pragma unroll
-    for (int c4 = 0; c4 < AT_DV / 4; ++c4)
-      op[c4] = make_float4(acc[4 * c4] * inv, acc[4 * c4 + 1] * inv, acc[4 * c4 + 2] * inv, acc[4 * c4 + 3] * inv);
-    lse[(size_t)b * Nq + qi] = m + logf(l);
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q_base + qb * 32 + c;
+    if (q < Nq) {
+      const float inv = 1.f / l[qb];
+      float* op = out + ((size_t)b * Nq + q) * AT_DV + 4 * h;        // O^T register 4 g + j <-> channel 8 g + 4 h + j
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(op + 8 * gq) =
+            make_float4(o[qb][4 * gq] * inv, o[qb][4 * gq + 1] * inv, o[qb][4 * gq + 2] * inv, o[qb][4 * gq + 3] * inv);
+      if (h == 0) lse[(size_t)b * Nq + q] = m[qb] + logf(l[qb]);
+    }
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
 // dq sweep: dtheta[i] = sum_j p_ij (dP_ij - delta_i) phi_j ; also writes delta_i = dO_i . O_i
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* theta, const float* phi, const float* g, const float* out,
-                                                     const float* lse, const float* dout, float* dtheta, float* delta, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) float ks[AT_KT * AT_DK];
-  __shared__ __attribute__((aligned(16))) float vs[AT_KT * AT_DV];
+template <int WAVES, int QB>
+__global__ __launch_bounds__(WAVES * 64) void k_attn_bwd_dq(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                            const float* __restrict__ g, const float* __restrict__ out,
+                                                            const float* __restrict__ lse, const float* __restrict__ dout,
+                                                            float* __restrict__ dtheta, float* __restrict__ delta, int Nq, int Nk) {
+  __shared__ float ks[AT_KT * AT_KS];
+  __shared__ float vs[AT_KT * AT_VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
   const int b = blockIdx.y;
-  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = qi < Nq;
-  const size_t row = (size_t)b * Nq + (live ? qi : 0);
-  float q[AT_DK], dq[AT_DK], dO[AT_DV];
+  const int q_base = (blockIdx.x * WAVES + wave) * (QB * 32);
+  float qf[QB][4], dof[QB][16], ls[QB], dl[QB];
+  f32x16 dq[QB];
 #pragma unroll
-  for (int d = 0; d < AT_DK; ++d) { q[d] = live ? theta[row * AT_DK + d] : 0.f; dq[d] = 0.f; }
-  float dl = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q_base + qb * 32 + c;
+    const bool live = q < Nq;
+    const size_t row = (size_t)b * Nq + (live ? q : 0);
 #pragma unroll
-  for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-    const float4 a = reinterpret_cast<const float4*>(dout + row * AT_DV)[c4];
-    const float4 o = reinterpret_cast<const float4*>(out + row * AT_DV)[c4];
-    dO[4 * c4] = a.x; dO[4 * c4 + 1] = a.y; dO[4 * c4 + 2] = a.z; dO[4 * c4 + 3] = a.w;
-    dl += a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
+    for (int t = 0; t < 4; ++t) qf[qb][t] = live ? theta[row * AT_DK + 2 * t + h] : 0.f;
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      dof[qb][t] = live ? dout[row * AT_DV + 2 * t + h] : 0.f;
+      part += dof[qb][t] * (live ? out[row * AT_DV + 2 * t + h] : 0.f);
+    }
+    dl[qb] = part + at_xor32(part);
+    ls[qb] = live ? lse[row] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[qb][r] = 0.f;
   }
-  const float ls = lse[row];
   for (int k0 = 0; k0 < Nk; k0 += AT_KT) {
     const int kn = min(AT_KT, Nk - k0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * AT_DK / 4; e += blockDim.x)
-      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
-          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = threadIdx.x; e < AT_KT * AT_DV / 4; e += blockDim.x)
-      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
-          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < AT_KT * AT_DK; e += WAVES * 64) {
+      const int key = e >> 3, d = e & 7;
+      ks[key * AT_KS + d] = key < kn ? phi[((size_t)b * Nk + k0 + key) * AT_DK + d] : 0.f;
+    }
+    for (int e = tid; e < AT_KT * AT_DV; e += WAVES * 64) {
+      const int key = e >> 5, cc = e & 31;
+      vs[key * AT_VS + cc] = key < kn ? g[((size_t)b * Nk + k0 + key) * AT_DV + cc] : 0.f;
+    }
     __syncthreads();
-    for (int j = 0; j < kn; ++j) {
-      const float4 ka = reinterpret_cast<const float4*>(ks)[j * 2], kb = reinterpret_cast<const float4*>(ks)[j * 2 + 1];
-      const float s = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
-      const float p = expf(s - ls);
-      float dp = 0.f;
-      const float4* vp = reinterpret_cast<const float4*>(vs + j * AT_DV);
+    const int nblk = (kn + 31) >> 5;
+    for (int kb = 0; kb < nblk; ++kb) {
+      float ka[4], vc[16], kt[16];
 #pragma unroll
-      for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-        const float4 v = vp[c4];
-        dp += dO[4 * c4] * v.x + dO[4 * c4 + 1] * v.y + dO[4 * c4 + 2] * v.z + dO[4 * c4 + 3] * v.w;
+      for (int t = 0; t < 4; ++t) ka[t] = ks[(kb * 32 + c) * AT_KS + 2 * t + h];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) vc[t] = vs[(kb * 32 + c) * AT_VS + 2 * t + h];          // A of dP^T = V dO^T: [key][c pair t]
+#pragma unroll
+      for (int u = 0; u < 16; ++u) kt[u] = ks[(kb * 32 + at_row(u, h)) * AT_KS + (c & 7)];  // A of dQ^T = K^T dS^T: [d][key pair u]
+      const bool ragged = kb * 32 + 32 > kn;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qf[qb][t], s, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[t], dof[qb][t], dp, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          float p = at_exp(s[u] - ls[qb]);
+          if (ragged && kb * 32 + at_row(u, h) >= kn) p = 0.f;
+          s[u] = p * (dp[u] - dl[qb]);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dq[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[u], s[u], dq[qb], 0, 0, 0);
       }
-      const float ds = p * (dp - dl);
-      dq[0] += ds * ka.x; dq[1] += ds * ka.y; dq[2] += ds * ka.z; dq[3] += ds * ka.w;
-      dq[4] += ds * kb.x; dq[5] += ds * kb.y; dq[6] += ds * kb.z; dq[7] += ds * kb.w;
     }
   }
-  if (live) {
-    float4* dp4 = reinterpret_cast<float4*>(dtheta + row * AT_DK);
-    dp4[0] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-    dp4[1] = make_float4(dq[4], dq[5], dq[6], dq[7]);
-    delta[row] = dl;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q_base + qb * 32 + c;
+    if (q < Nq) {
+      const size_t row = (size_t)b * Nq + q;      // dQ^T register r (< 4) of half h <-> d = 4 h + r
+      *reinterpret_cast<float4*>(dtheta + row * AT_DK + 4 * h) = make_float4(dq[qb][0], dq[qb][1], dq[qb][2], dq[qb][3]);
+      if (h == 0) delta[row] = dl[qb];
+    }
   }
 }
 
-// dkv sweep: lane = key j: dg_j = sum_i p_ij dO_i ; dphi_j = sum_i p_ij (dP_ij - delta_i) theta_i
-#define AT_QREC 44   // per-query LDS record: theta[8], dO[32], lse, delta, pad to 16-byte multiple
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* theta, const float* phi, const float* g, const float* lse,
-                                                      const float* dout, const float* delta, float* dphi, float* dg, int Nq, int Nk,
-                                                      int q_chunk) {
-  // gridDim.z > 1: the query range is split over z (small batches would otherwise leave most CUs idle) and the
-  // partial dphi/dg rows are added with float atomics into pre-zeroed outputs
-  __shared__ __attribute__((aligned(16))) float qs[AT_KT * AT_QREC];
+// ---------------------------------------------------------------------------------------------------------------
+// dkv sweep, lane = key: dg_j = sum_i p_ij dO_i ; dphi_j = sum_i p_ij (dP_ij - delta_i) theta_i.
+// gridDim.z > 1: the query range is split over z (small batches would otherwise leave most CUs idle) and the partial
+// dphi / dg rows are added with float atomics into pre-zeroed outputs.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_attn_bwd_dkv(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                             const float* __restrict__ g, const float* __restrict__ lse,
+                                                             const float* __restrict__ dout, const float* __restrict__ delta,
+                                                             float* __restrict__ dphi, float* __restrict__ dg, int Nq, int Nk, int q_chunk) {
+  __shared__ float qs[AT_QT * AT_KS];
+  __shared__ float dos[AT_QT * AT_VS];
+  __shared__ __attribute__((aligned(16))) float lss[AT_QT];
+  __shared__ __attribute__((aligned(16))) float des[AT_QT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
   const int q_begin = blockIdx.z * q_chunk, q_end = min(Nq, q_begin + q_chunk);
   const int b = blockIdx.y;
-  const int kj = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = kj < Nk;
-  const size_t krow = (size_t)b * Nk + (live ? kj : 0);
-  float k[AT_DK], v[AT_DV], dk[AT_DK], dv[AT_DV];
+  const int key = (blockIdx.x * WAVES + wave) * 32 + c;
+  const bool live = key < Nk;
+  const size_t krow = (size_t)b * Nk + (live ? key : 0);
+  float kf[4], vf[16];
 #pragma unroll
-  for (int d = 0; d < AT_DK; ++d) { k[d] = phi[krow * AT_DK + d]; dk[d] = 0.f; }
+  for (int t = 0; t < 4; ++t) kf[t] = live ? phi[krow * AT_DK + 2 * t + h] : 0.f;
 #pragma unroll
-  for (int c = 0; c < AT_DV; ++c) { v[c] = g[krow * AT_DV + c]; dv[c] = 0.f; }
-  for (int q0 = q_begin; q0 < q_end; q0 += AT_KT) {
-    const int qn = min(AT_KT, q_end - q0);
+  for (int t = 0; t < 16; ++t) vf[t] = live ? g[krow * AT_DV + 2 * t + h] : 0.f;
+  f32x16 dv, dk;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+  for (int q0 = q_begin; q0 < q_end; q0 += AT_QT) {
+    const int qn = min(AT_QT, q_end - q0);
     __syncthreads();
-    for (int e = threadIdx.x; e < AT_KT * 2; e += blockDim.x) {       // theta: 2 float4 per query
-      const int i = e >> 1, h = e & 1;
-      reinterpret_cast<float4*>(qs + i * AT_QREC)[h] =
-          i < qn ? reinterpret_cast<const float4*>(theta + ((size_t)b * Nq + q0 + i) * AT_DK)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < AT_QT * AT_DK; e += WAVES * 64) {
+      const int i = e >> 3, d = e & 7;
+      qs[i * AT_KS + d] = i < qn ? theta[((size_t)b * Nq + q0 + i) * AT_DK + d] : 0.f;
     }
-    for (int e = threadIdx.x; e < AT_KT * 8; e += blockDim.x) {       // dO: 8 float4 per query
-      const int i = e >> 3, h = e & 7;
-      reinterpret_cast<float4*>(qs + i * AT_QREC + 8)[h] =
-          i < qn ? reinterpret_cast<const float4*>(dout + ((size_t)b * Nq + q0 + i) * AT_DV)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < AT_QT * AT_DV; e += WAVES * 64) {
+      const int i = e >> 5, cc = e & 31;
+      dos[i * AT_VS + cc] = i < qn ? dout[((size_t)b * Nq + q0 + i) * AT_DV + cc] : 0.f;
     }
-    for (int i = threadIdx.x; i < AT_KT; i += blockDim.x) {
-      qs[i * AT_QREC + 40] = i < qn ? lse[(size_t)b * Nq + q0 + i] : INFINITY;   // p = exp(s - inf) = 0 for padding
-      qs[i * AT_QREC + 41] = i < qn ? delta[(size_t)b * Nq + q0 + i] : 0.f;
+    for (int i = tid; i < AT_QT; i += WAVES * 64) {
+      lss[i] = i < qn ? lse[(size_t)b * Nq + q0 + i] : INFINITY;      // p = exp(s - inf) = 0 for padding
+      des[i] = i < qn ? delta[(size_t)b * Nq + q0 + i] : 0.f;
     }
     __syncthreads();
-    for (int i = 0; i < qn; ++i) {
-      const float4* r = reinterpret_cast<const float4*>(qs + i * AT_QREC);
-      const float4 qa = r[0], qb = r[1];
-      const float s = k[0] * qa.x + k[1] * qa.y + k[2] * qa.z + k[3] * qa.w + k[4] * qb.x + k[5] * qb.y + k[6] * qb.z + k[7] * qb.w;
-      const float4 tail = r[10];
-      const float p = expf(s - tail.x);
-      float dp = 0.f;
+    const int nblk = (qn + 31) >> 5;
+    for (int qb = 0; qb < nblk; ++qb) {
+      f32x16 s, dp;
 #pragma unroll
-      for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-        const float4 a = r[2 + c4];
-        dp += a.x * v[4 * c4] + a.y * v[4 * c4 + 1] + a.z * v[4 * c4 + 2] + a.w * v[4 * c4 + 3];
-        dv[4 * c4] += p * a.x; dv[4 * c4 + 1] += p * a.y; dv[4 * c4 + 2] += p * a.z; dv[4 * c4 + 3] += p * a.w;
-      }
-      const float ds = p * (dp - tail.y);
-      dk[0] += ds * qa.x; dk[1] += ds * qa.y; dk[2] += ds * qa.z; dk[3] += ds * qa.w;
-      dk[4] += ds * qb.x; dk[5] += ds * qb.y; dk[6] += ds * qb.z; dk[7] += ds * qb.w;
-    }
-  }
-  if (live && gridDim.z > 1) {
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int d = 0; d < AT_DK; ++d) atomicAdd(dphi + krow * AT_DK + d, dk[d]);
+      for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[(qb * 32 + c) * AT_KS + 2 * t + h], kf[t], s, 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < AT_DV; ++c) atomicAdd(dg + krow * AT_DV + c, dv[c]);
-  } else if (live) {
-    float4* dp4 = reinterpret_cast<float4*>(dphi + krow * AT_DK);
-    dp4[0] = make_float4(dk[0], dk[1], dk[2], dk[3]);
-    dp4[1] = make_float4(dk[4], dk[5], dk[6], dk[7]);
-    float4* dg4 = reinterpret_cast<float4*>(dg + krow * AT_DV);
+      for (int t = 0; t < 16; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dos[(qb * 32 + c) * AT_VS + 2 * t + h], vf[t], dp, 0, 0, 0);
 #pragma unroll
-    for (int c4 = 0; c4 < AT_DV / 4; ++c4) dg4[c4] = make_float4(dv[4 * c4], dv[4 * c4 + 1], dv[4 * c4 + 2], dv[4 * c4 + 3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Small-batch variants (per-GPU batches of the 8-way data-parallel shard): 64 queries per workgroup, and the FOUR
-// waves of the workgroup split the KEYS of those queries (wave w takes key tiles w, w+4, ...), each with a private
-// LDS tile; the partial softmax states are merged through LDS at the end.  4x the parallelism of one wave per 64
-// queries, a quarter of the serial key loop.
-// ------------------------------------------------------------------------------------------
-#define AT_KS 64    // keys per wave-private LDS tile
-
-__global__ __launch_bounds__(256) void k_attn_fwd_ks(const float* theta, const float* phi, const float* g, float* out, float* lse,
-                                                     int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) float sm[4 * AT_KS * (AT_DK + AT_DV)];      // 40 KB: 4 x (K tile + V tile)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* ks = sm + wave * AT_KS * (AT_DK + AT_DV);
-  float* vs = ks + AT_KS * AT_DK;
-  const int b = blockIdx.y;
-  const int qi = blockIdx.x * 64 + lane;
-  const bool live = qi < Nq;
-  float q[AT_DK];
+      for (int gq = 0; gq < 4; ++gq) {           // registers 4 g .. 4 g + 3 <-> queries 8 g + 4 h + 0 .. 3
+        const float4 l4 = *reinterpret_cast<const float4*>(lss + qb * 32 + 8 * gq + 4 * h);
+        const float4 d4 = *reinterpret_cast<const float4*>(des + qb * 32 + 8 * gq + 4 * h);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-  for (int d = 0; d < AT_DK; ++d) q[d] = live ? theta[((size_t)b * Nq + qi) * AT_DK + d] : 0.f;
-  float m = -INFINITY, l = 0.f, acc[AT_DV];
-#pragma unroll
-  for (int c = 0; c < AT_DV; ++c) acc[c] = 0.f;
-
-  for (int k0 = wave * AT_KS; k0 < Nk; k0 += 4 * AT_KS) {        // wave-uniform trip count; no workgroup barrier inside
-    const int kn = min(AT_KS, Nk - k0);
-    for (int e = lane; e < AT_KS * AT_DK / 4; e += 64)
-      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
-          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = lane; e < AT_KS * AT_DV / 4; e += 64)
-      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
-          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_wave_barrier();
-    for (int j0 = 0; j0 < kn; j0 += 8) {
-      float s[8];
-      float mx = m;
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float4 ka = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2];
-        const float4 kb = reinterpret_cast<const float4*>(ks)[(j0 + jj) * 2 + 1];
-        float t = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
-        if (j0 + jj >= kn) t = -INFINITY;
-        s[jj] = t;
-        mx = fmaxf(mx, t);
-      }
-      const float sc = expf(m - mx);
-      l *= sc;
-#pragma unroll
-      for (int c = 0; c < AT_DV; ++c) acc[c] *= sc;
-      m = mx;
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float p = expf(s[jj] - m);
-        l += p;
-        const float4* vp = reinterpret_cast<const float4*>(vs + (j0 + jj) * AT_DV);
-#pragma unroll
-        for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-          const float4 v = vp[c4];
-          acc[4 * c4 + 0] += p * v.x; acc[4 * c4 + 1] += p * v.y; acc[4 * c4 + 2] += p * v.z; acc[4 * c4 + 3] += p * v.w;
+        for (int j = 0; j < 4; ++j) {
+          const float p = at_exp(s[4 * gq + j] - lv[j]);
+          s[4 * gq + j] = p;
+          dp[4 * gq + j] = p * (dp[4 * gq + j] - dvv[j]);
         }
       }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        dv = __builtin_amdgcn_mfma_f32_32x32x2f32(dos[(qb * 32 + at_row(u, h)) * AT_VS + c], s[u], dv, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qs[(qb * 32 + at_row(u, h)) * AT_KS + (c & 7)], dp[u], dk, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
   }
-  // merge the four partial states of each query: sm is re-used as part[w][34][64]
-  __syncthreads();
-  float* part = sm + wave * (AT_DV + 2) * 64;
-  part[0 * 64 + lane] = m;
-  part[1 * 64 + lane] = l;
+  if (live) {
+    float* gp = dg + krow * AT_DV + 4 * h;        // dV^T register 4 g + j <-> channel 8 g + 4 h + j
+    float* kp = dphi + krow * AT_DK + 4 * h;      // dK^T register r (< 4) <-> d = 4 h + r
+    if (gridDim.z > 1) {
 #pragma unroll
-  for (int c = 0; c < AT_DV; ++c) part[(2 + c) * 64 + lane] = acc[c];
-  __syncthreads();
-  if (wave == 0 && live) {
-    float ms = -INFINITY;
+      for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-    for (int w = 0; w < 4; ++w) ms = fmaxf(ms, sm[w * (AT_DV + 2) * 64 + lane]);
-    float lt = 0.f, o[AT_DV];
+        for (int j = 0; j < 4; ++j) atomicAdd(gp + 8 * gq + j, dv[4 * gq + j]);
 #pragma unroll
-    for (int c = 0; c < AT_DV; ++c) o[c] = 0.f;
+      for (int j = 0; j < 4; ++j) atomicAdd(kp + j, dk[j]);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float* pw = sm + w * (AT_DV + 2) * 64;
-      const float f = expf(pw[lane] - ms);          // exp(-inf) = 0 for a wave that saw no key
-      lt += pw[64 + lane] * f;
-#pragma unroll
-      for (int c = 0; c < AT_DV; ++c) o[c] += pw[(2 + c) * 64 + lane] * f;
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(gp + 8 * gq) = make_float4(dv[4 * gq], dv[4 * gq + 1], dv[4 * gq + 2], dv[4 * gq + 3]);
+      *reinterpret_cast<float4*>(kp) = make_float4(dk[0], dk[1], dk[2], dk[3]);
     }
-    const float inv = 1.f / lt;
-    float4* op = reinterpret_cast<float4*>(out + ((size_t)b * Nq + qi) * AT_DV);
-#pragma unroll
-    for (int c4 = 0; c4 < AT_DV / 4; ++c4)
-      op[c4] = make_float4(o[4 * c4] * inv, o[4 * c4 + 1] * inv, o[4 * c4 + 2] * inv, o[4 * c4 + 3] * inv);
-    lse[(size_t)b * Nq + qi] = ms + logf(lt);
   }
 }
 
-__global__ __launch_bounds__(256) void k_attn_bwd_dq_ks(const float* theta, const float* phi, const float* g, const float* out,
-                                                        const float* lse, const float* dout, float* dtheta, float* delta, int Nq, int Nk) {
-  __shared__ __attribute__((aligned(16))) float sm[4 * AT_KS * (AT_DK + AT_DV)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* ks = sm + wave * AT_KS * (AT_DK + AT_DV);
-  float* vs = ks + AT_KS * AT_DK;
-  const int b = blockIdx.y;
-  const int qi = blockIdx.x * 64 + lane;
-  const bool live = qi < Nq;
-  const size_t row = (size_t)b * Nq + (live ? qi : 0);
-  float q[AT_DK], dq[AT_DK], dO[AT_DV];
-#pragma unroll
-  for (int d = 0; d < AT_DK; ++d) { q[d] = live ? theta[row * AT_DK + d] : 0.f; dq[d] = 0.f; }
-  float dl = 0.f;
-#pragma unroll
-  for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-    const float4 a = reinterpret_cast<const float4*>(dout + row * AT_DV)[c4];
-    const float4 o = reinterpret_cast<const float4*>(out + row * AT_DV)[c4];
-    dO[4 * c4] = a.x; dO[4 * c4 + 1] = a.y; dO[4 * c4 + 2] = a.z; dO[4 * c4 + 3] = a.w;
-    dl += a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
-  }
-  const float ls = lse[row];
-  for (int k0 = wave * AT_KS; k0 < Nk; k0 += 4 * AT_KS) {
-    const int kn = min(AT_KS, Nk - k0);
-    for (int e = lane; e < AT_KS * AT_DK / 4; e += 64)
-      reinterpret_cast<float4*>(ks)[e] = (e * 4 < kn * AT_DK)
-          ? reinterpret_cast<const float4*>(phi + ((size_t)b * Nk + k0) * AT_DK)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = lane; e < AT_KS * AT_DV / 4; e += 64)
-      reinterpret_cast<float4*>(vs)[e] = (e * 4 < kn * AT_DV)
-          ? reinterpret_cast<const float4*>(g + ((size_t)b * Nk + k0) * AT_DV)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < kn; ++j) {
-      const float4 ka = reinterpret_cast<const float4*>(ks)[j * 2], kb = reinterpret_cast<const float4*>(ks)[j * 2 + 1];
-      const float s = q[0] * ka.x + q[1] * ka.y + q[2] * ka.z + q[3] * ka.w + q[4] * kb.x + q[5] * kb.y + q[6] * kb.z + q[7] * kb.w;
-      const float p = expf(s - ls);
-      float dp = 0.f;
-      const float4* vp = reinterpret_cast<const float4*>(vs + j * AT_DV);
-#pragma unroll
-      for (int c4 = 0; c4 < AT_DV / 4; ++c4) {
-        const float4 v = vp[c4];
-        dp += dO[4 * c4] * v.x + dO[4 * c4 + 1] * v.y + dO[4 * c4 + 2] * v.z + dO[4 * c4 + 3] * v.w;
-      }
-      const float ds = p * (dp - dl);
-      dq[0] += ds * ka.x; dq[1] += ds * ka.y; dq[2] += ds * ka.z; dq[3] += ds * ka.w;
-      dq[4] += ds * kb.x; dq[5] += ds * kb.y; dq[6] += ds * kb.z; dq[7] += ds * kb.w;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();                       // partial dq of the four key slices: plain sum (lse is already final)
-  float* part = sm + wave * AT_DK * 64;
-#pragma unroll
-  for (int d = 0; d < AT_DK; ++d) part[d * 64 + lane] = dq[d];
-  __syncthreads();
-  if (wave == 0 && live) {
-    float r[AT_DK];
-#pragma unroll
-    for (int d = 0; d < AT_DK; ++d)
-      r[d] = sm[d * 64 + lane] + sm[(AT_DK + d) * 64 + lane] + sm[(2 * AT_DK + d) * 64 + lane] + sm[(3 * AT_DK + d) * 64 + lane];
-    float4* dp4 = reinterpret_cast<float4*>(dtheta + row * AT_DK);
-    dp4[0] = make_float4(r[0], r[1], r[2], r[3]);
-    dp4[1] = make_float4(r[4], r[5], r[6], r[7]);
-    delta[row] = dl;
-  }
+// Queries per workgroup: the widest configuration that still fills two rounds of the 256 CUs
+static inline int at_q_cfg(int Nq, int B) {
+  if ((long)sg_cdiv(Nq, 256) * B >= 512) return 256;
+  if ((long)sg_cdiv(Nq, 128) * B >= 512) return 128;
+  return 32;
 }
-
-// one lane per row; 64-lane workgroups when 256-lane ones would leave most of the 256 CUs idle
-static inline int at_threads(int rows, int B) { return (long)sg_cdiv(rows, 256) * B >= 1024 ? 256 : 64; }
 
 // theta [B,Nq,8], phi [B,Nk,8], g [B,Nk,32] -> out [B,Nq,32], lse [B,Nq]
 extern "C" int sg_attention_fwd(const float* theta, const float* phi, const float* g, float* out, float* lse, int B, int Nq,
                                 int Nk, int dk, int dv, void* stream) {
   if (!theta || !phi || !g || !out || !lse || dk != AT_DK || dv != AT_DV || Nk < 1) return SG_ERR_ARG;
-  const int tq = at_threads(Nq, B);
-  if (tq == 64)      // small batch: 64 queries per workgroup, keys split over its four waves
-    hipLaunchKernelGGL(k_attn_fwd_ks, dim3(sg_cdiv(Nq, 64), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
-  else
-    hipLaunchKernelGGL(k_attn_fwd, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, Nq, Nk);
+  if (B < 1 || Nq < 1) return SG_OK;
+  const int cfg = at_q_cfg(Nq, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (cfg == 256) hipLaunchKernelGGL((k_attn_fwd<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else if (cfg == 128) hipLaunchKernelGGL((k_attn_fwd<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else hipLaunchKernelGGL((k_attn_fwd<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, Nq, Nk);
   return sg_launch_status();
 }
 
@@ -384,24 +333,38 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
                                 int dk, int dv, void* stream) {
   if (!theta || !phi || !g || !out || !lse || !dout || !dtheta || !dphi || !dg || !delta || dk != AT_DK || dv != AT_DV || Nk < 1)
     return SG_ERR_ARG;
-  const int tq = at_threads(Nq, B), tk = at_threads(Nk, B);
-  if (tq == 64)
-    hipLaunchKernelGGL(k_attn_bwd_dq_ks, dim3(sg_cdiv(Nq, 64), B), dim3(256), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
-                       dtheta, delta, Nq, Nk);
+  if (B < 1 || Nq < 1) return SG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int cfg = at_q_cfg(Nq, B);
+  if (cfg == 256)
+    hipLaunchKernelGGL((k_attn_bwd_dq<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+  else if (cfg == 128)
+    hipLaunchKernelGGL((k_attn_bwd_dq<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(sg_cdiv(Nq, tq), B), dim3(tq), 0, (hipStream_t)stream, theta, phi, g, out, lse, dout,
-                       dtheta, delta, Nq, Nk);
-  const long kblocks = (long)sg_cdiv(Nk, tk) * B;
-  int zs = kblocks >= 1024 ? 1 : (int)((1024 + kblocks - 1) / kblocks);
+    hipLaunchKernelGGL((k_attn_bwd_dq<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+  // key sweep: every workgroup stages ALL queries of its z slice, so the more keys it owns the better that is amortised:
+  // the widest of 128 / 64 / 32 keys per workgroup that still gives two rounds of workgroups and wastes the fewest padded
+  // key lanes; then split the query range until the grid fills the chip
+  int kw = 1;
+  long best_pad = -1;
+  for (int w = 4; w >= 1; w >>= 1) {
+    const long blocks = (long)sg_cdiv(Nk, 32 * w) * B;
+    const long pad = (long)sg_cdiv(Nk, 32 * w) * 32 * w - Nk;
+    if (blocks >= 512 && (best_pad < 0 || pad < best_pad)) { kw = w; best_pad = pad; }
+  }
+  const long kblocks = (long)sg_cdiv(Nk, 32 * kw) * B;
+  int zs = kblocks >= 512 ? 1 : (int)((512 + kblocks - 1) / kblocks);
   if (zs > 16) zs = 16;
-  int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_KT) * AT_KT;        // whole LDS tiles per z slice
+  int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_QT) * AT_QT;        // whole LDS tiles per z slice
   zs = sg_cdiv(Nq, q_chunk);
   if (zs > 1) {
-    if (hipMemsetAsync(dphi, 0, sizeof(float) * (size_t)B * Nk * AT_DK, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(dg, 0, sizeof(float) * (size_t)B * Nk * AT_DV, (hipStream_t)stream) != hipSuccess)
+    if (hipMemsetAsync(dphi, 0, sizeof(float) * (size_t)B * Nk * AT_DK, s) != hipSuccess ||
+        hipMemsetAsync(dg, 0, sizeof(float) * (size_t)B * Nk * AT_DV, s) != hipSuccess)
       return SG_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(sg_cdiv(Nk, tk), B, zs), dim3(tk), 0, (hipStream_t)stream, theta, phi, g, lse, dout,
-                     delta, dphi, dg, Nq, Nk, q_chunk);
+  const dim3 grid(sg_cdiv(Nk, 32 * kw), B, zs);
+  if (kw == 4) hipLaunchKernelGGL((k_attn_bwd_dkv<4>), grid, dim3(256), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
+  else if (kw == 2) hipLaunchKernelGGL((k_attn_bwd_dkv<2>), grid, dim3(128), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
+  else hipLaunchKernelGGL((k_attn_bwd_dkv<1>), grid, dim3(64), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
   return sg_launch_status();
 }

@@ -89,6 +89,73 @@ extern "C" int sg_cvt_bf16(const float* x, void* out, long n, int relu, const fl
   return sg_launch_status();
 }
 
+// Same conversion of a [M, C] gradient (rows = pixels) fused with its bias gradient: dbias[c] += sum_m rowscale[sample(m)] * x[m][c]
+// (fp32 sums of the scaled fp32 values, before the bf16 rounding) -- ONE sweep over dy instead of three (convert,
+// scaled fp32 copy, column sums).  CL column lanes of 8 channels x RL row lanes per workgroup, LDS tree over the row lanes.
+__global__ __launch_bounds__(256) void k_cvt_bf16_bias(const float* __restrict__ x, u16* __restrict__ out, long M, int C,
+                                                       const float* __restrict__ rowscale, long rows_per_sample, float* __restrict__ dbias,
+                                                       int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int c8 = C >> 3;
+  int CL = 256;
+  while (CL > c8) CL >>= 1;
+  const int RL = 256 / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const long m0 = (long)blockIdx.x * rows_per_block;
+  const long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  for (int cg0 = 0; cg0 < c8; cg0 += CL) {
+    const int cg = cg0 + cl;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cg < c8) {
+      for (long m = m0 + rl; m < m1; m += RL) {
+        const float4* src = reinterpret_cast<const float4*>(x + m * C + 8 * cg);
+        float4 v0 = src[0], v1 = src[1];
+        if (rowscale) {
+          const float f = rowscale[m / rows_per_sample];
+          v0.x *= f; v0.y *= f; v0.z *= f; v0.w *= f; v1.x *= f; v1.y *= f; v1.z *= f; v1.w *= f;
+        }
+        bf16x8 hh;
+        hh[0] = (__bf16)v0.x; hh[1] = (__bf16)v0.y; hh[2] = (__bf16)v0.z; hh[3] = (__bf16)v0.w;
+        hh[4] = (__bf16)v1.x; hh[5] = (__bf16)v1.y; hh[6] = (__bf16)v1.z; hh[7] = (__bf16)v1.w;
+        *reinterpret_cast<bf16x8*>(out + m * C + 8 * cg) = hh;
+        s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w; s[4] += v1.x; s[5] += v1.y; s[6] += v1.z; s[7] += v1.w;
+      }
+    }
+    if (RL > 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] = s[j];
+      __syncthreads();
+      for (int st = RL >> 1; st > 0; st >>= 1) {
+        if (rl < st) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] += red[j * 256 + threadIdx.x + st * CL];
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = red[j * 256 + threadIdx.x];
+      __syncthreads();
+    }
+    if (rl == 0 && cg < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(dbias + 8 * cg + j, s[j]);
+    }
+  }
+}
+
+// x fp32 [M, C] -> out bf16 [M, C] (times rowscale[m / rows_per_sample] when given), dbias [C] += column sums of the scaled
+// fp32 values; C % 8 == 0.
+extern "C" int sg_cvt_bf16_bias(const float* x, void* out, long M, int C, const float* rowscale, long rows_per_sample, float* dbias,
+                                void* stream) {
+  if (!x || !out || !dbias || M < 0 || C <= 0 || (C & 7) || (rowscale && rows_per_sample <= 0)) return SG_ERR_ARG;
+  if (M == 0) return SG_OK;
+  long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
+  const int rpb = (int)(r < 32 ? 32 : r);
+  hipLaunchKernelGGL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, M, C, rowscale,
+                     rows_per_sample, dbias, rpb);
+  return sg_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------
 constexpr int SG2_BM = 256, SG2_BK = 64;
 constexpr int SG2_TILE = SG2_BM * SG2_BK * 2;                 // bytes of a 256-row operand tile (32 KB)

@@ -317,6 +317,17 @@ def cvt_bf16(t: torch.Tensor, relu=False, rowscale=None) -> torch.Tensor:
     return out
 
 
+def cvt_bf16_bias(t: torch.Tensor, rowscale, db: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of (rowscale[b] *) t [B,H,W,C] and db [C] += its fp32 column sums, in one sweep (sg_cvt_bf16_bias)."""
+    _chk(t, rowscale, db)
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    C = t.shape[-1]
+    M = t.numel() // C
+    with _hbm("cvt_bf16", t, out):
+        call("sg_cvt_bf16_bias", _p(t), out.data_ptr(), M, C, _p(rowscale), (M // rowscale.numel()) if rowscale is not None else 1, _p(db), _stream())
+    return out
+
+
 def bf16_of(t: torch.Tensor) -> torch.Tensor:
     """The bf16 twin of an fp32 activation (made on first use)."""
     t16 = _twin_get(t)
@@ -443,11 +454,25 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
         # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy; the bias
         # gradient (fp32 sums of the scaled dy) is its own memory-bound sweep
         x16 = bf16_of(x)
-        dy16 = bf16_of(dy) if sample_scale is None else bf16_scaled(dy, sample_scale)
+        fused_db = False
+        if sample_scale is None:
+            dy16 = _twin_get(dy)
+            if dy16 is None and db is not None:          # one sweep over dy: bf16 twin + bias gradient
+                dy16 = cvt_bf16_bias(dy, None, db)
+                _twin_put(dy, dy16)
+                fused_db = True
+            elif dy16 is None:
+                dy16 = bf16_of(dy)
+        else:
+            key = (dy.untyped_storage().data_ptr(), sample_scale.data_ptr(), dy.storage_offset(), dy.numel())
+            if key not in _TWINS and db is not None:     # ... with the per-sample factors applied on the way
+                _TWINS[key] = (dy, sample_scale, cvt_bf16_bias(dy, sample_scale, db))
+                fused_db = True
+            dy16 = bf16_scaled(dy, sample_scale)
         with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
             call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same),
                  _flags(relu_in), _stream())
-        if db is not None:
+        if db is not None and not fused_db:
             bias_grad(dy if sample_scale is None else rowscale(dy, sample_scale), db)
         return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,

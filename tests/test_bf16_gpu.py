@@ -210,3 +210,22 @@ def test_conv2d_transpose_bf16(dev, gen, bf16_mode, B, H, W, Cin, Cout, k, strid
     O.conv2d_transpose(xr, r16(w), None, stride).backward(r16(dy))
     dx = ops.conv2d_transpose_bwd_data(g32(dy, dev), wg, stride=stride, mask=xg)
     close(dx, xr.grad * (x > 0), 5e-5, "convT dgrad (mask) vs bf16-rounded-operand oracle")
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_cvt_bf16_bias_fused_sweep(dev, scaled):
+    """sg_cvt_bf16_bias: bf16 twin of (per-sample factor x) dy and the fp32 bias gradient in one sweep; the bf16 weight-grad
+    path takes it when no twin of dy exists yet.  Twin bit-exact against torch's rounding of the fp32 product, column sums
+    against fp64."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, H, W, C = 7, 5, 9, 192                        # rows not a multiple of the row lanes, C / 8 = 24 column lanes (not a power of two)
+    dy = torch.randn(B, H, W, C, device=dev, generator=g)
+    sc = (torch.rand(B, device=dev, generator=g) * 2 - 0.5) if scaled else None
+    db = torch.full((C,), 0.25, device=dev)
+    t16 = ops.cvt_bf16_bias(dy, sc, db)
+    prod = dy if sc is None else dy * sc.view(B, 1, 1, 1)
+    assert torch.equal(t16.view(torch.int16), prod.to(torch.bfloat16).view(torch.int16))
+    ref = prod.double().sum(dim=(0, 1, 2)) + 0.25
+    err = (db.double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item(), err

@@ -31,7 +31,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int at_row(int u, int h) { return (u & 3) + 8 * (u >> 2) + 4 * h; }   // accumulator register -> tile row
 // exp(x) = 2^(x log2 e) on v_exp_f32, with the rounding error of the product (and of the constant) folded back in: the
 // plain product is off by up to |x| * 6e-8 in the exponent, i.e. 2e-6 relative at x = -50; this form stays within ~2 ulp
-__device__ __forceinline__ float at_exp(float x) {
+// (x is clamped at -104: exp is 0 there in fp32, and -inf -- a masked key, the running maximum before the first block -- would
+// otherwise give inf - inf in the error term)
+__device__ __forceinline__ float at_exp(float xin) {
+  const float x = fmaxf(xin, -104.f);
   const float t = x * 1.44269502162933349609375f;                                    // float(log2 e)
   const float e = __builtin_fmaf(x, 1.44269502162933349609375f, -t) + x * 1.925963033500011e-8f;   // + x * (log2 e - float(log2 e))
   const float p = __builtin_amdgcn_exp2f(t);

@@ -219,7 +219,8 @@ def test_full_state_save_and_resume(dev, tmp_path):
         # +-lr, so a component whose gradient is ~0 may step the other way: a handful of entries differ by up to 2 lr,
         # the mean difference stays orders of magnitude below lr.  A state that was NOT restored moves every entry by O(lr).
         diff = (ma.store.flat - mc.store.flat).abs()
-        assert diff.max().item() <= 1e-3 and diff.mean().item() <= 2e-5, (ma.name, diff.max().item(), diff.mean().item())
+        # (worst case: a component that steps the other way in each of the 3 steps = 3 x 2 lr = 1.2e-3)
+        assert diff.max().item() <= 3 * 2 * 2e-4 * 1.1 and diff.mean().item() <= 2e-5, (ma.name, diff.max().item(), diff.mean().item())
         assert (ma.store.state - mc.store.state).abs().max().item() <= 1e-5, ma.name
         for k in ("m", "v"):
             sa, sc = oa.flat_state(ma.store)[k], oc.flat_state(mc.store)[k]

@@ -19,7 +19,7 @@ echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_write.log 2>&1
 echo write done
 CMD="rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py --no-cpu-baseline --no-kernel-timing --steps 1 --warmup 1"
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel sg_igemm_kernel \
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel sg_igemm \
   --command "$CMD" --out $O/igemm_traffic_bs128.json > $O/traffic.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel sg_wgrad_kernel \
   --command "$CMD" --out $O/wgrad_traffic_bs128.json >> $O/traffic.log 2>&1
@@ -33,4 +33,13 @@ python3 $R/tools/pmc_traffic.py $O/pmc_fetch16/run_counter_collection.csv $O/pmc
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch16/run_counter_collection.csv $O/pmc_write16/run_counter_collection.csv --kernel sg_wgrad_bf16v2_kernel \
   --command "$CMD --conv-dtype bf16 --batch 256" --out $O/wgrad_bf16_traffic_bs256.json >> $O/traffic.log 2>&1
 rm -f $O/pmc_fetch16/run_counter_collection.csv $O/pmc_write16/run_counter_collection.csv $O/*/run_kernel_trace.csv.bak
+# clock and matrix-pipe occupancy of the conv kernels on one layer (GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES), the bare
+# MFMA rates of this device and the constant / per-k-tile split of the DMA-fed kernels
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/clk -o run -- python3 $R/tools/probe_clock.py run > $O/clk.log 2>&1
+python3 $R/tools/probe_clock.py report $O/clk/run_counter_collection.csv > $O/probe_clock.txt
+rm -rf $O/clk
+echo clock probe done
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak $R/tools/mfma_peak.hip 2>/dev/null && timeout -k 10 240 /tmp/mfma_peak > $O/mfma_peak.txt
+echo mfma peak done
+timeout -k 10 240 python3 $R/tools/probe_ktile.py > $O/probe_ktile.txt 2>&1
 echo profile pass done

@@ -175,6 +175,47 @@ __global__ __launch_bounds__(512, 2) void k_loop(const float* src, float* sink, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc_out += acc[i][r];
   }
+  if (MODE == 13) {   // as 7, the eight max() of a step batched in front of its 16 MFMAs (separate registers)
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 512) lds[i] = s[i & 15];
+    __syncthreads();
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 af[2][4], bf[2][2];
+    const int ifloor = s[15] > 2.f ? 0 : (int)0x80000000;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + 8u * (threadIdx.x & 63);
+    for (int i = 0; i < 4; ++i) { af[0][i] = f32x2{s[i], s[i + 1]}; af[1][i] = f32x2{s[i + 2], s[i + 3]}; }
+    for (int i = 0; i < 2; ++i) { bf[0][i] = f32x2{s[8 + i], s[9 + i]}; bf[1][i] = f32x2{s[10 + i], s[11 + i]}; }
+    auto mma13 = [&](int slot) {
+      float ar[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ar[e][i] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, af[slot][i][e]), ifloor));
+      SB();
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[e][i], bf[slot][j][e], acc[i * 2 + j], 0, 0, 0);
+    };
+#define STEP13(slot_next, slot_cur, o) do { READ6(slot_next, o); asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); SB(); mma13(slot_cur); SB(); } while (0)
+    t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    READ6(0, 0);
+    for (int it = 0; it < iters / 16; ++it) {
+      STEP13(1, 0, 4096); STEP13(0, 1, 8192); STEP13(1, 0, 12288); STEP13(0, 1, 16384); STEP13(1, 0, 20480); STEP13(0, 1, 24576); STEP13(1, 0, 28672);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      READ6(0, 0);
+      SB();
+      mma13(1);
+      SB();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc_out += acc[i][r];
+  }
   if (MODE == 9 || MODE == 10) {   // bf16 32x32x16 with six ds_read_b128 per 8 MFMAs: grouped in front (9) or spread (10); barrier per 4 steps
     __shared__ float lds[16384];
     for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = s[i & 15];
@@ -286,6 +327,7 @@ int main() {
   run<8>("f32 ... reads spread between the MFMAs", 2.0 * 32 * 32 * 2, 8, src, sink, stamps);
   run<11>("f32 ... spread reads, no barrier", 2.0 * 32 * 32 * 2, 8, src, sink, stamps);
   run<12>("f32 ... spread reads, barrier, no max()", 2.0 * 32 * 32 * 2, 8, src, sink, stamps);
+  run<13>("f32 ... in-front reads, 8 max() batched per step", 2.0 * 32 * 32 * 2, 8, src, sink, stamps);
   run<9>("bf16 32x32x16 + 6 ds_read_b128 in front", 2.0 * 32 * 32 * 16, 8, src, sink, stamps);
   run<10>("bf16 32x32x16 + 6 ds_read_b128 spread", 2.0 * 32 * 32 * 16, 8, src, sink, stamps);
   return 0;

@@ -466,28 +466,39 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     SG4_DSR(bf4[slot][0], b4[s], (st) * BTILE + 0 * 4096);                                   \
     SG4_DSR(bf4[slot][1], b4[s], (st) * BTILE + 1 * 4096);                                   \
   } while (0)
+  // ReLU: ONE v_max_i32 per element on the bit pattern (negative floats are negative integers; fmaxf / v_med3 come with a
+  // canonicalising pre-pass, inline asm would hide the VALU -> MFMA hazard from hipcc: no s_nop, NaNs -- seen), applied IN
+  // PLACE to the whole fragment set in front of the step's MFMAs: a max in front of every MFMA pair costs 9 % of the fp32
+  // matrix rate (dependent VALU + s_nop in every gap; tools/mfma_peak.hip: 154 -> 141 TFLOP/s), batched it costs 2 %
+  auto relu4 = [&](int slot) {
+    if constexpr (RELU) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float x = af4[slot][i][e];      // (a scalar copy first: __builtin_bit_cast applied to a vector ELEMENT reads element 0)
+          af4[slot][i][e] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, x), 0));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto mma4 = [&](int slot) {
+    relu4(slot);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float a = af4[slot][i][e];
-        // ReLU as ONE v_max_i32 on the bit pattern (negative floats are negative integers); fmaxf / v_med3 come with a
-        // canonicalising pre-pass, inline asm would hide the VALU -> MFMA hazard from hipcc (no s_nop: NaNs, seen)
-        if constexpr (RELU) a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), 0));
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf4[slot][j][e], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af4[slot][i][e], bf4[slot][j][e], acc[i][j], 0, 0, 0);
   };
   auto mma4_dma = [&](int slot, int st) {
+    relu4(slot);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        float a = af4[slot][i][e];
-        if constexpr (RELU) a = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, a), 0));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf4[slot][j][e], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af4[slot][i][e], bf4[slot][j][e], acc[i][j], 0, 0, 0);
         if (e == 0) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void k_loop(const float* src, float* sink, 
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ar[e][i] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, af[slot][i][e]), ifloor));
+        for (int i = 0; i < 4; ++i) { const float x_ = af[slot][i][e]; ar[e][i] = __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, x_), ifloor)); }
       SB();
 #pragma unroll
       for (int e = 0; e < 2; ++e)

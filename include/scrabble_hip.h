@@ -85,9 +85,10 @@ int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, fl
  *      the caller then uses sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor. ----------------------- */
 int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream);
 /* sg_cvt_bf16 of a [M, C] gradient fused with its bias gradient (resnet_ops.py:65 bias of the conv whose weight-grad
- * follows): out bf16 = rowscale[m / rows_per_sample] * x (rowscale nullable), dbias[c] += the fp32 column sums of the scaled
- * values.  C % 8 == 0. */
-int sg_cvt_bf16_bias(const float* x, void* out, long M, int C, const float* rowscale, long rows_per_sample, float* dbias, void* stream);
+ * follows): out bf16 = rowscale[m / rows_per_sample] * x (rowscale nullable), out_plain (nullable) bf16 = x unscaled (the
+ * data-grad operand of the same gradient), dbias[c] += the fp32 column sums of the scaled values.  C % 8 == 0. */
+int sg_cvt_bf16_bias(const float* x, void* out, void* out_plain, long M, int C, const float* rowscale, long rows_per_sample,
+                     float* dbias, void* stream);
 int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, const void* mask16, float* dx, void* dx16,

@@ -92,9 +92,9 @@ extern "C" int sg_cvt_bf16(const float* x, void* out, long n, int relu, const fl
 // Same conversion of a [M, C] gradient (rows = pixels) fused with its bias gradient: dbias[c] += sum_m rowscale[sample(m)] * x[m][c]
 // (fp32 sums of the scaled fp32 values, before the bf16 rounding) -- ONE sweep over dy instead of three (convert,
 // scaled fp32 copy, column sums).  CL column lanes of 8 channels x RL row lanes per workgroup, LDS tree over the row lanes.
-__global__ __launch_bounds__(256) void k_cvt_bf16_bias(const float* __restrict__ x, u16* __restrict__ out, long M, int C,
-                                                       const float* __restrict__ rowscale, long rows_per_sample, float* __restrict__ dbias,
-                                                       int rows_per_block) {
+__global__ __launch_bounds__(256) void k_cvt_bf16_bias(const float* __restrict__ x, u16* __restrict__ out, u16* __restrict__ out_plain, long M,
+                                                       int C, const float* __restrict__ rowscale, long rows_per_sample,
+                                                       float* __restrict__ dbias, int rows_per_block) {
   __shared__ float red[256 * 8];
   const int c8 = C >> 3;
   int CL = 256;
@@ -110,6 +110,12 @@ __global__ __launch_bounds__(256) void k_cvt_bf16_bias(const float* __restrict__
       for (long m = m0 + rl; m < m1; m += RL) {
         const float4* src = reinterpret_cast<const float4*>(x + m * C + 8 * cg);
         float4 v0 = src[0], v1 = src[1];
+        if (out_plain) {
+          bf16x8 hp;
+          hp[0] = (__bf16)v0.x; hp[1] = (__bf16)v0.y; hp[2] = (__bf16)v0.z; hp[3] = (__bf16)v0.w;
+          hp[4] = (__bf16)v1.x; hp[5] = (__bf16)v1.y; hp[6] = (__bf16)v1.z; hp[7] = (__bf16)v1.w;
+          *reinterpret_cast<bf16x8*>(out_plain + m * C + 8 * cg) = hp;
+        }
         if (rowscale) {
           const float f = rowscale[m / rows_per_sample];
           v0.x *= f; v0.y *= f; v0.z *= f; v0.w *= f; v1.x *= f; v1.y *= f; v1.z *= f; v1.w *= f;
@@ -143,16 +149,16 @@ __global__ __launch_bounds__(256) void k_cvt_bf16_bias(const float* __restrict__
   }
 }
 
-// x fp32 [M, C] -> out bf16 [M, C] (times rowscale[m / rows_per_sample] when given), dbias [C] += column sums of the scaled
-// fp32 values; C % 8 == 0.
-extern "C" int sg_cvt_bf16_bias(const float* x, void* out, long M, int C, const float* rowscale, long rows_per_sample, float* dbias,
-                                void* stream) {
+// x fp32 [M, C] -> out bf16 [M, C] (times rowscale[m / rows_per_sample] when given), out_plain (nullable) bf16 [M, C] = the
+// unscaled copy, dbias [C] += column sums of the scaled fp32 values; C % 8 == 0.
+extern "C" int sg_cvt_bf16_bias(const float* x, void* out, void* out_plain, long M, int C, const float* rowscale, long rows_per_sample,
+                                float* dbias, void* stream) {
   if (!x || !out || !dbias || M < 0 || C <= 0 || (C & 7) || (rowscale && rows_per_sample <= 0)) return SG_ERR_ARG;
   if (M == 0) return SG_OK;
   long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
   const int rpb = (int)(r < 32 ? 32 : r);
-  hipLaunchKernelGGL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, M, C, rowscale,
-                     rows_per_sample, dbias, rpb);
+  hipLaunchKernelGGL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, (u16*)out_plain, M, C,
+                     rowscale, rows_per_sample, dbias, rpb);
   return sg_launch_status();
 }
 

@@ -285,7 +285,7 @@ def bf16_scaled(t: torch.Tensor, rowscale: torch.Tensor) -> torch.Tensor:
     key = (t.untyped_storage().data_ptr(), rowscale.data_ptr(), t.storage_offset(), t.numel())
     e = _TWINS.get(key)
     if e is None:
-        e = (t, rowscale, cvt_bf16(t, rowscale=rowscale))
+        e = (t, rowscale, cvt_bf16(t, rowscale=rowscale), None)
         _TWINS[key] = e
     return e[2]
 
@@ -317,15 +317,43 @@ def cvt_bf16(t: torch.Tensor, relu=False, rowscale=None) -> torch.Tensor:
     return out
 
 
-def cvt_bf16_bias(t: torch.Tensor, rowscale, db: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of (rowscale[b] *) t [B,H,W,C] and db [C] += its fp32 column sums, in one sweep (sg_cvt_bf16_bias)."""
+def cvt_bf16_bias(t: torch.Tensor, rowscale, db: torch.Tensor, want_plain: bool = False):
+    """bf16 copy of (rowscale[b] *) t [B,H,W,C] and db [C] += its fp32 column sums, in one sweep (sg_cvt_bf16_bias);
+    want_plain: -> (scaled copy, unscaled copy), both written in that sweep."""
     _chk(t, rowscale, db)
     out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    plain = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16) if want_plain else None
     C = t.shape[-1]
     M = t.numel() // C
-    with _hbm("cvt_bf16", t, out):
-        call("sg_cvt_bf16_bias", _p(t), out.data_ptr(), M, C, _p(rowscale), (M // rowscale.numel()) if rowscale is not None else 1, _p(db), _stream())
-    return out
+    with _hbm("cvt_bf16", t, out, plain):
+        call("sg_cvt_bf16_bias", _p(t), out.data_ptr(), None if plain is None else plain.data_ptr(), M, C, _p(rowscale),
+             (M // rowscale.numel()) if rowscale is not None else 1, _p(db), _stream())
+    return (out, plain) if want_plain else out
+
+
+def grad_operand(dy: torch.Tensor, sample_scale, want_colsum: bool):
+    """The bf16 weight-grad operand of a gradient tensor: (bf16 copy of sample_scale[b] * dy[b], fp32 column sums of it or
+    None).  Whatever is missing -- the scaled copy, the column sums (= the bias gradient of every conv that produced dy's
+    forward tensor: conv2 and the 1x1 shortcut of a ResNetBlockDown share them) and, when the gradient has no plain twin yet,
+    that twin too (the data-grad launch of the same gradient wants it) -- is made in ONE sweep over dy and kept for the step."""
+    key = (dy.untyped_storage().data_ptr(), 0 if sample_scale is None else sample_scale.data_ptr(), dy.storage_offset(), dy.numel())
+    e = _TWINS.get(key)
+    plain = _twin_get(dy)
+    if e is None or (want_colsum and e[3] is None):
+        whole = dy.storage_offset() == 0 and dy.numel() * 4 == dy.untyped_storage().nbytes()
+        colsum = torch.zeros(dy.shape[-1], device=dy.device, dtype=torch.float32)
+        if sample_scale is None:
+            t16 = cvt_bf16_bias(dy, None, colsum)
+            if plain is None:
+                _twin_put(dy, t16)
+        elif plain is None and whole:
+            t16, p16 = cvt_bf16_bias(dy, sample_scale, colsum, want_plain=True)
+            _twin_put(dy, p16)
+        else:
+            t16 = cvt_bf16_bias(dy, sample_scale, colsum)
+        e = (dy, sample_scale, t16, colsum)
+        _TWINS[key] = e
+    return e[2], e[3]
 
 
 def bf16_of(t: torch.Tensor) -> torch.Tensor:
@@ -451,29 +479,19 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
     if USE_V2 and _low() and (same or kh * kw == 1) and ((Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)):
-        # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy; the bias
-        # gradient (fp32 sums of the scaled dy) is its own memory-bound sweep
+        # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy, whose
+        # conversion sweep also yields the bias gradient (fp32 column sums) and, if missing, the plain twin for the data-grad
         x16 = bf16_of(x)
-        fused_db = False
-        if sample_scale is None:
-            dy16 = _twin_get(dy)
-            if dy16 is None and db is not None:          # one sweep over dy: bf16 twin + bias gradient
-                dy16 = cvt_bf16_bias(dy, None, db)
-                _twin_put(dy, dy16)
-                fused_db = True
-            elif dy16 is None:
-                dy16 = bf16_of(dy)
-        else:
-            key = (dy.untyped_storage().data_ptr(), sample_scale.data_ptr(), dy.storage_offset(), dy.numel())
-            if key not in _TWINS and db is not None:     # ... with the per-sample factors applied on the way
-                _TWINS[key] = (dy, sample_scale, cvt_bf16_bias(dy, sample_scale, db))
-                fused_db = True
+        if db is None and sample_scale is None:
+            dy16 = bf16_of(dy)
+        elif db is None:
             dy16 = bf16_scaled(dy, sample_scale)
+        else:
+            dy16, colsum = grad_operand(dy, sample_scale, True)
+            add(db, colsum, out=db)
         with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
             call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same),
                  _flags(relu_in), _stream())
-        if db is not None and not fused_db:
-            bias_grad(dy if sample_scale is None else rowscale(dy, sample_scale), db)
         return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("wgrad", B, H, W, Cin, Cout, kh)):

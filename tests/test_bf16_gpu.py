@@ -223,9 +223,34 @@ def test_cvt_bf16_bias_fused_sweep(dev, scaled):
     dy = torch.randn(B, H, W, C, device=dev, generator=g)
     sc = (torch.rand(B, device=dev, generator=g) * 2 - 0.5) if scaled else None
     db = torch.full((C,), 0.25, device=dev)
-    t16 = ops.cvt_bf16_bias(dy, sc, db)
+    t16, p16 = ops.cvt_bf16_bias(dy, sc, db, want_plain=True)
     prod = dy if sc is None else dy * sc.view(B, 1, 1, 1)
     assert torch.equal(t16.view(torch.int16), prod.to(torch.bfloat16).view(torch.int16))
+    assert torch.equal(p16.view(torch.int16), dy.to(torch.bfloat16).view(torch.int16))       # the unscaled twin of the same sweep
     ref = prod.double().sum(dim=(0, 1, 2)) + 0.25
     err = (db.double() - ref).abs().max().item()
     assert err <= 1e-5 * ref.abs().max().item(), err
+
+
+def test_grad_operand_bundle_shared_by_conv2_and_shortcut(dev, bf16_mode):
+    """ops.grad_operand: the two weight-grads that share a gradient (conv2 and the 1x1 shortcut of a ResNetBlockDown) get the
+    same scaled bf16 copy and the same column sums from ONE sweep; both bias gradients equal the fp64 sums; the plain twin for
+    the data-grad launch comes out of that sweep as well."""
+    ops = bf16_mode
+    g = torch.Generator(device=dev).manual_seed(9)
+    B, H, W, Cin, Cout = 4, 8, 10, 64, 256
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    c1 = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    sc = torch.rand(B, device=dev, generator=g) + 0.5
+    ops.new_step()
+    dw2, db2 = torch.zeros(3, 3, Cout, Cout, device=dev), torch.zeros(Cout, device=dev)
+    dws, dbs = torch.zeros(1, 1, Cin, Cout, device=dev), torch.full((Cout,), 2.0, device=dev)
+    ops.conv2d_bwd_weight(c1, dy, dw2, relu_in=True, db=db2, sample_scale=sc)
+    n_entries = len(ops._TWINS)
+    ops.conv2d_bwd_weight(x, dy, dws, db=dbs, sample_scale=sc)
+    assert len(ops._TWINS) == n_entries + 1                     # only x's twin is new: dy's bundle was reused
+    ref = (dy.double() * sc.double().view(B, 1, 1, 1)).sum(dim=(0, 1, 2))
+    assert (db2.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert (dbs.double() - 2.0 - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.equal(ops._twin_get(dy).view(torch.int16), dy.to(torch.bfloat16).view(torch.int16))

@@ -303,7 +303,7 @@ def main():
                                     "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
                                     "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
                                     "kernel": ("sg_igemm_bf16v2_kernel / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16, fp8 32x32x64 in fp8 mode; <= 32-filter convs stay fp32)"
-                                               if bf16 else "sg_igemm_kernel (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
+                                               if bf16 else "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
                                     "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
                                     "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
                 line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),

@@ -310,10 +310,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_attn_bwd_dkv(const float* __rest
   }
 }
 
-// Queries per workgroup: the widest configuration that still fills two rounds of the 256 CUs
+// Queries per workgroup: the widest configuration (the key tiles are staged once per workgroup) that still gives every CU work
 static inline int at_q_cfg(int Nq, int B) {
   if ((long)sg_cdiv(Nq, 256) * B >= 512) return 256;
-  if ((long)sg_cdiv(Nq, 128) * B >= 512) return 128;
+  if ((long)sg_cdiv(Nq, 128) * B >= 320) return 128;
+  if ((long)sg_cdiv(Nq, 64) * B >= 320) return 64;
   return 32;
 }
 
@@ -326,6 +327,7 @@ extern "C" int sg_attention_fwd(const float* theta, const float* phi, const floa
   hipStream_t s = (hipStream_t)stream;
   if (cfg == 256) hipLaunchKernelGGL((k_attn_fwd<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
   else if (cfg == 128) hipLaunchKernelGGL((k_attn_fwd<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else if (cfg == 64) hipLaunchKernelGGL((k_attn_fwd<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, Nq, Nk);
   else hipLaunchKernelGGL((k_attn_fwd<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, Nq, Nk);
   return sg_launch_status();
 }
@@ -343,6 +345,8 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
     hipLaunchKernelGGL((k_attn_bwd_dq<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else if (cfg == 128)
     hipLaunchKernelGGL((k_attn_bwd_dq<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+  else if (cfg == 64)
+    hipLaunchKernelGGL((k_attn_bwd_dq<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else
     hipLaunchKernelGGL((k_attn_bwd_dq<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   // key sweep: every workgroup stages ALL queries of its z slice, so the more keys it owns the better that is amortised:
@@ -353,10 +357,10 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   for (int w = 4; w >= 1; w >>= 1) {
     const long blocks = (long)sg_cdiv(Nk, 32 * w) * B;
     const long pad = (long)sg_cdiv(Nk, 32 * w) * 32 * w - Nk;
-    if (blocks >= 512 && (best_pad < 0 || pad < best_pad)) { kw = w; best_pad = pad; }
+    if (blocks >= 320 && (best_pad < 0 || pad < best_pad)) { kw = w; best_pad = pad; }
   }
   const long kblocks = (long)sg_cdiv(Nk, 32 * kw) * B;
-  int zs = kblocks >= 512 ? 1 : (int)((512 + kblocks - 1) / kblocks);
+  int zs = kblocks >= 320 ? 1 : (int)((512 + kblocks - 1) / kblocks);
   if (zs > 16) zs = 16;
   int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_QT) * AT_QT;        // whole LDS tiles per z slice
   zs = sg_cdiv(Nq, q_chunk);

@@ -293,10 +293,10 @@ def test_filterbank(dev, gen):
     close(dz, z.grad, tol=5e-5, name="dz")
 
 
-# B = 2: the small-batch kernels (64 queries per workgroup, keys split over its four waves, partial states merged
-# through LDS); B = 260 with Nq = 1024: >= 1024 workgroups of 256 queries -> the one-lane-per-query kernels of the
-# full-batch step; (200, 300): more than four 64-key tiles per wave and ragged tails
-@pytest.mark.parametrize("B,Nq,Nk", [(2, 128, 32), (2, 384, 96), (2, 640, 160), (2, 300, 77), (3, 200, 300), (260, 1024, 72)])
+# B = 2: 32 queries / 32 keys per workgroup and the z-split of the key sweep; B = 260 with Nq = 1024: 256 queries per workgroup
+# (the full-batch step); (200, 300): several key tiles and ragged tails; (20 | 48, 1280, 320): the discriminator site at the
+# 8-way shard sizes -> 64 / 128 queries per workgroup
+@pytest.mark.parametrize("B,Nq,Nk", [(2, 128, 32), (2, 384, 96), (2, 640, 160), (2, 300, 77), (3, 200, 300), (260, 1024, 72), (20, 1280, 320), (48, 1280, 320)])
 def test_attention(dev, gen, B, Nq, Nk):
     from scrabble_gan_amd import ops
     th = (rnd(gen, B, Nq, 8) * 1.5).requires_grad_(True)

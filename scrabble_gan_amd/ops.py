@@ -813,7 +813,7 @@ def attention_fwd(theta, phi, g):
     Nk, dv = g.shape[1], g.shape[2]
     out = empty(B, Nq, dv, like=theta)
     lse = empty(B, Nq, like=theta)
-    with _hbm("attention_fwd", theta, phi, g, out, flops=2.0 * B * Nq * Nk * (dk + dv), roof="valu"):
+    with _hbm("attention_fwd", theta, phi, g, out, flops=2.0 * B * Nq * Nk * (dk + dv), roof="mfma_f32"):
         call("sg_attention_fwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), B, Nq, Nk, dk, dv, _stream())
     return out, lse
 
@@ -824,7 +824,7 @@ def attention_bwd(theta, phi, g, out, lse, dout):
     Nk, dv = g.shape[1], g.shape[2]
     dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
     delta = empty(B, Nq, like=theta)
-    with _hbm("attention_bwd", theta, phi, g, out, dout, dtheta, dphi, dg, flops=2.0 * B * Nq * Nk * (3 * dk + 2 * dv + dv), roof="valu"):
+    with _hbm("attention_bwd", theta, phi, g, out, dout, dtheta, dphi, dg, flops=2.0 * B * Nq * Nk * (3 * dk + 2 * dv + dv), roof="mfma_f32"):
         call("sg_attention_bwd", _p(theta), _p(phi), _p(g), _p(out), _p(lse), _p(dout), _p(dtheta), _p(dphi), _p(dg), _p(delta),
              B, Nq, Nk, dk, dv, _stream())
     return dtheta, dphi, dg

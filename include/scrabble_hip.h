@@ -99,6 +99,11 @@ int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float*
  * Cout % 256 == 0) or Cin == Cout == 64: the caller then uses sg_conv2d_bwd_weight. */
 int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
                                 int kh, int kw, int pad_same, int flags, void* stream);
+/* bf16 weight gradient of layers.Conv2DTranspose (resnet_ops.py:57,69; contract of sg_conv2d_transpose_bwd_weight with bf16
+ * operand copies): x16 [B,H,W,Cin], dy16 [B,sh*H,sw*W,Cout], dw fp32 [kh,kw,Cout,Cin] +=.  (Cout, Cin) % (256,256), (64,256) or
+ * (64,64) == 0 and H*W >= 64, else SG_ERR_UNSUPPORTED. */
+int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
+                                          int kh, int kw, int sh, int sw, void* stream);
 
 /* ---- fp8 (OCP e4m3) operands for the forward / data-grad convolutions (BASELINE config c5, first slice): per-tensor
  *      scaling operand8 = e4m3(value * 448 / amax), amax = max|tensor| kept as a DEVICE scalar (no host sync), fp32

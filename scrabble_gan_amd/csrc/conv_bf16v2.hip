@@ -899,10 +899,12 @@ struct SgWgrad2Args {
   int ntaps, flags;    // SG_RELU_IN applies to P
   int mchunk;          // pixels per workgroup (multiple of 64)
   int c_tiles, n_tiles, nchunks;
+  int p_sy, p_sx;      // STRIDED kernels only: P lives on the (p_sy H) x (p_sx W) grid and pixel (y, x) of the base grid reads
+                       // P at (p_sy y + dy, p_sx x + dx) -- the gradient operand of a transposed convolution
   SgTap taps[SG_MAX_TAPS];
 };
 
-template <int CT, int NT>
+template <int CT, int NT, bool STRIDED>
 __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr bool PA = CT == 64, QA = NT == 64;        // image (a) operands
@@ -940,6 +942,8 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
   const int HW = p.H * p.W;
   constexpr bool SAMEROLE = (PA == QA) && (NP == NQ);   // P and Q rows of a lane coincide: one pixel cursor serves both
   int ry[NP], rx[NP];          // (y, x) cursor of the pixel this lane loads for P instruction i in the CURRENT load tile
+  int ppix[STRIDED ? NP : 1];  // STRIDED: index of the P pixel (tap included) on P's own grid
+  const int Hs = p.p_sy * p.H, Ws = p.p_sx * p.W;
   int rmp[NP], rmq[SAMEROLE ? 1 : NQ];       // pixel indices of its P / Q rows, relative to m_begin
   unsigned cswp[NP], cswq[NQ]; // byte offset of its (swizzled) chunk inside the pixel's channel vector (before c0 / n0)
   auto role = [&](bool img_a, int i, int& row, unsigned& csw) {
@@ -963,6 +967,7 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
     const int rem = (int)(mm % HW);
     ry[i] = rem / p.W;
     rx[i] = rem - ry[i] * p.W;
+    if constexpr (STRIDED) ppix[i] = ((int)(mm / HW) * Hs + p.p_sy * ry[i] + tdy) * Ws + p.p_sx * rx[i] + tdx;
   }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -973,8 +978,10 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
   const int m_len = (int)(m_end - m_begin);
   const int adv_y = (64 % HW) / p.W, adv_x = (64 % HW) % p.W;       // cursor advance of 64 pixels (within one image plane)
   const int Hh = p.H;
-  const unsigned long long p_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 2ull * (unsigned)c0 + 2ull * (unsigned long long)m_begin * p.Cp;
+  const unsigned long long p_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.p) + 2ull * (unsigned)c0 +
+                                      (STRIDED ? 0ull : 2ull * (unsigned long long)m_begin * p.Cp);
   const unsigned long long q_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.q) + 2ull * (unsigned)n0 + 2ull * (unsigned long long)m_begin * p.Cq;
+  const int pp_adv = p.p_sy * Ws * adv_y + p.p_sx * adv_x, pp_wrap = Ws * (p.p_sy - 1);      // STRIDED: advance of ppix per tile / per x wrap
   const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
   const long tap_shift = (long)tdy * p.W + tdx;                      // pixel shift of the tap (may be negative)
   // LDS: P stage 0 | P stage 1 | Q stage 0 | Q stage 1
@@ -982,9 +989,9 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
   auto issue_part = [&](int st, int i) {
     if (i < NP) {
       const bool live = rmp[i] < m_len;
-      const int sy = ry[i] + tdy, sx = rx[i] + tdx;
-      const bool okp = live && sy >= 0 && sy < Hh && sx >= 0 && sx < p.W;
-      const unsigned long long pa = p_base64 + (unsigned long long)(((long)rmp[i] + tap_shift) * p.Cp * 2) + cswp[i];
+      const int sy = (STRIDED ? p.p_sy * ry[i] : ry[i]) + tdy, sx = (STRIDED ? p.p_sx * rx[i] : rx[i]) + tdx;
+      const bool okp = live && sy >= 0 && sy < (STRIDED ? Hs : Hh) && sx >= 0 && sx < (STRIDED ? Ws : p.W);
+      const unsigned long long pa = p_base64 + (unsigned long long)((STRIDED ? (long)ppix[STRIDED ? i : 0] : (long)rmp[i] + tap_shift) * p.Cp * 2) + cswp[i];
       const unsigned plo = okp ? (unsigned)pa : (unsigned)z_base64, phi = okp ? (unsigned)(pa >> 32) : (unsigned)(z_base64 >> 32);
       const unsigned char* src_p = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)phi << 32) | plo));
       const int ii = 8 * i + wave;
@@ -994,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
       rx[i] += adv_x;
       const int wx = rx[i] >= p.W ? 1 : 0;
       rx[i] -= wx * p.W;
+      if constexpr (STRIDED) ppix[i] += pp_adv + wx * pp_wrap;
       ry[i] += adv_y + wx;
       ry[i] -= ry[i] >= Hh ? Hh : 0;
     }
@@ -1200,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void sg_wgrad_bf16v2_kernel(const SgWgrad2A
   }
 }
 
-template <int CT, int NT>
+template <int CT, int NT, bool STRIDED = false>
 static int sg2_launch_wgrad(SgWgrad2Args a, long M, hipStream_t s) {
   a.c_tiles = a.Cp / CT;
   a.n_tiles = a.Cq / NT;
@@ -1229,13 +1237,13 @@ static int sg2_launch_wgrad(SgWgrad2Args a, long M, hipStream_t s) {
   constexpr int LDS_BYTES = 2 * 64 * CT * 2 + 2 * 64 * NT * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_bf16v2_kernel<CT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_wgrad_bf16v2_kernel<CT, NT, STRIDED>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_wgrad_bf16v2_kernel<CT, NT>), dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((sg_wgrad_bf16v2_kernel<CT, NT, STRIDED>), dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, s, a);
   return sg_launch_status();
 }
 
@@ -1252,7 +1260,7 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   if (2L * M * Cin >= (1L << 40) || 2L * M * Cout >= (1L << 40)) return SG_ERR_UNSUPPORTED;
   SgWgrad2Args a{};
   a.p = (const u16*)x16; a.q = (const u16*)dy16; a.dw = dw;
-  a.Bn = B; a.H = H; a.W = W; a.Cp = Cin; a.Cq = Cout; a.ntaps = kh * kw; a.flags = flags;
+  a.Bn = B; a.H = H; a.W = W; a.Cp = Cin; a.Cq = Cout; a.ntaps = kh * kw; a.flags = flags; a.p_sy = 1; a.p_sx = 1;
   const int ph = kh / 2, pw = kw / 2;
   for (int ky = 0; ky < kh; ++ky)
     for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
@@ -1261,6 +1269,30 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   if (Cout % 256 == 0) return sg2_launch_wgrad<64, 256>(a, M, s);
   if (Cin == 64 && Cout == 64) return sg2_launch_wgrad<64, 64>(a, M, s);
   return SG_ERR_UNSUPPORTED;
+}
+
+// Weight gradient of a transposed convolution (resnet_ops.py:57,69): dw [kh,kw,Cout,Cin] += sum over the INPUT pixels (b,i,j)
+// of dy[b, sh i + ky - pad, sw j + kx - pad, co] * x[b,i,j,ci] -- the stride-1 kernel with the roles swapped (P = dy on its
+// own, finer grid, read with a stride; Q = x) and the taps of sg_conv2d_transpose_bwd_weight.
+// x16 bf16 [B,H,W,Cin], dy16 bf16 [B,sh H,sw W,Cout]; (Cout, Cin) % (256, 256), (64, 256) or (64, 64) == 0 and H W >= 64, else
+// SG_ERR_UNSUPPORTED.
+extern "C" int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
+                                                     int kh, int kw, int sh, int sw, void* stream) {
+  if (!x16 || !dy16 || !dw || kh * kw > SG_MAX_TAPS || sh < 1 || sw < 1) return SG_ERR_ARG;
+  if ((Cin % 64) || (Cout % 64) || H * W < 64) return SG_ERR_UNSUPPORTED;
+  const long M = (long)B * H * W;
+  if (M <= 0) return SG_OK;
+  if ((long)B * sh * H * sw * W >= (1L << 31) || 2L * M * Cin >= (1L << 40)) return SG_ERR_UNSUPPORTED;
+  SgWgrad2Args a{};
+  a.p = (const u16*)dy16; a.q = (const u16*)x16; a.dw = dw;
+  a.Bn = B; a.H = H; a.W = W; a.Cp = Cout; a.Cq = Cin; a.ntaps = kh * kw; a.flags = 0; a.p_sy = sh; a.p_sx = sw;
+  const int pbh = sh == 1 ? kh / 2 : 0, pbw = sw == 1 ? kw / 2 : 0;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - pbh, kx - pbw, (ky * kw + kx) * Cin * Cout};
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout % 256 == 0 && Cin % 256 == 0) return sg2_launch_wgrad<256, 256, true>(a, M, s);
+  if (Cin % 256 == 0) return sg2_launch_wgrad<64, 256, true>(a, M, s);
+  return sg2_launch_wgrad<64, 64, true>(a, M, s);
 }
 
 // ==========================================================================================================

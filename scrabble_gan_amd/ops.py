@@ -544,6 +544,11 @@ def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
     kh, kw, Cout, wc = dw.shape
     assert wc == Cin
     sh, sw = stride
+    if USE_V2 and _low() and Cin % 64 == 0 and Cout % 64 == 0 and H * W >= 64:
+        x16, dy16 = bf16_of(x), bf16_of(dy)
+        with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_wgrad", B, H, W, Cin, Cout, kh)):
+            call("sg_conv2d_transpose_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, _stream())
+        return
     with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_wgrad", B, H, W, Cin, Cout, kh)):
         call("sg_conv2d_transpose_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, 0, _stream())
 

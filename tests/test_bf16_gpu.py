@@ -254,3 +254,23 @@ def test_grad_operand_bundle_shared_by_conv2_and_shortcut(dev, bf16_mode):
     assert (db2.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     assert (dbs.double() - 2.0 - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     assert torch.equal(ops._twin_get(dy).view(torch.int16), dy.to(torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride", [
+    (2, 8, 10, 512, 256, 3, (2, 2)),       # G block 1 shape class: 256 x 256 tiles, two Cin tiles
+    (3, 8, 12, 256, 128, 3, (2, 2)),       # 64 x 256 tiles (two Cout tiles of 64); M = 288 pixels: ragged last tile of 64
+    (2, 8, 16, 128, 64, 3, (2, 2)),        # 64 x 64 tiles with two Cin tiles
+    (2, 8, 10, 256, 256, 1, (2, 2)),       # the 1x1 stride-2 shortcut
+    (2, 16, 5, 256, 256, 3, (2, 1)),       # anisotropic stride (the generator's last up block keeps the height)
+])
+def test_conv2d_transpose_weight_grad_bf16(dev, gen, bf16_mode, B, H, W, Cin, Cout, k, stride):
+    """bf16 weight gradient of Conv2DTranspose (sg_conv2d_transpose_bwd_weight_bf16v2: the DMA-fed weight-grad kernel reading
+    the gradient on its own, finer grid with a stride) against the oracle on bf16-rounded operands, accumulating into dw."""
+    ops = bf16_mode
+    x = rnd(gen, B, H, W, Cin)
+    dy = rnd(gen, B, stride[0] * H, stride[1] * W, Cout)
+    w = (rnd(gen, k, k, Cout, Cin) * 0).requires_grad_(True)
+    O.conv2d_transpose(r16(x), w, None, stride).backward(r16(dy))
+    dw = torch.full((k, k, Cout, Cin), 0.5, device=dev)
+    ops.conv2d_transpose_bwd_weight(g32(x, dev), g32(dy, dev), dw, stride=stride)
+    close(dw - 0.5, w.grad, 1e-4, "convT weight-grad vs bf16-rounded-operand oracle")

@@ -209,7 +209,7 @@ def test_conv_transpose_vs_oracle_at_launch_geometry(dev, conv_mode, H, W, Cin, 
         dw = torch.zeros_like(w)
         ops.conv2d_transpose_bwd_weight(x, dy, dw, stride=stride)
         tot = torch.zeros(k, k, Cout, Cin, dtype=torch.float64)
-        xc, dyc = x.double().cpu(), dy.double().cpu()
+        xc, dyc = rq_d(x.cpu()).double(), rq_d(dy.cpu()).double()      # (bf16 mode: the weight-grad rounds both operands too, round 2)
         for lo in range(0, B, 32):
             wz = torch.zeros(k, k, Cout, Cin, dtype=torch.float64, requires_grad=True)
             O.conv2d_transpose(xc[lo:lo + 32], wz, None, stride).backward(dyc[lo:lo + 32])

@@ -482,71 +482,82 @@ int sg_launch_igemm(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// thin convolutions (Cin == 1 or Cout == 1): HBM-bound direct kernels, no matrix cores
+// thin convolutions (Cin == 1 or Cout == 1): HBM-bound direct kernels, no matrix cores.
+// Round 2 (expand, thin weight-grad): the one-channel rows a row of output needs are staged in LDS, so nothing in the inner loop is
+// a dependent, bounds-checked global load (round 1: 1.9 TB/s of output for the expansion, now 4.7-5.4).
 // ------------------------------------------------------------------------------------------
+struct SgThinWin { int dy0, nrows, dx0, span; };      // tap window: rows dy0 .. dy0 + nrows - 1, columns dx0 .. dx0 + span - Wg
+
+static SgThinWin sg_thin_window(const SgThinArgs& a) {
+  int dy0 = a.taps[0].dy, dy1 = dy0, dx0 = a.taps[0].dx, dx1 = dx0;
+  for (int t = 1; t < a.ntaps; ++t) {
+    dy0 = a.taps[t].dy < dy0 ? a.taps[t].dy : dy0; dy1 = a.taps[t].dy > dy1 ? a.taps[t].dy : dy1;
+    dx0 = a.taps[t].dx < dx0 ? a.taps[t].dx : dx0; dx1 = a.taps[t].dx > dx1 ? a.taps[t].dx : dx1;
+  }
+  return SgThinWin{dy0, dy1 - dy0 + 1, dx0, a.Wg + dx1 - dx0};
+}
+
 // expand: out[m, c] = sum_t a1[pix(m)+tap_t] * w_t[c] + bias[c]      (a has ONE channel)
-__global__ __launch_bounds__(256) void sg_thin_expand_kernel(const SgThinArgs p) {
-  const int cq = p.C >> 2;  // float4 groups per pixel; divides 256
-  const long M = (long)p.Bn * p.Hg * p.Wg;
-  const int HW = p.Hg * p.Wg;
-  const long gtid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long gsz = (long)gridDim.x * blockDim.x;
-  const int c = 4 * (int)(gtid % cq);
+// One output row (b, y) per workgroup iteration: the nrows input rows it needs are staged in LDS (zero outside the image, ReLU
+// applied), then thread (channel group, pixel lane) walks the row: per output float4 a handful of LDS broadcasts and FMAs and
+// one 16-byte store -- the kernel is a write stream.
+__global__ __launch_bounds__(256) void sg_thin_expand_kernel(const SgThinArgs p, const SgThinWin win) {
+  extern __shared__ float rows[];       // [nrows][span]
+  const int cq = p.C >> 2, lanes = 256 / cq;          // cq divides 256
+  const int cl = threadIdx.x % cq, pl = threadIdx.x / cq, c = 4 * cl;
   float4 wv[SG_MAX_TAPS];
+  int toff[SG_MAX_TAPS];
 #pragma unroll
-  for (int t = 0; t < SG_MAX_TAPS; ++t)
-    wv[t] = t < p.ntaps ? *reinterpret_cast<const float4*>(p.w + p.taps[t].w_off + c)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < SG_MAX_TAPS; ++t) {
+    wv[t] = t < p.ntaps ? *reinterpret_cast<const float4*>(p.w + p.taps[t].w_off + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    toff[t] = t < p.ntaps ? (p.taps[t].dy - win.dy0) * win.span + p.taps[t].dx - win.dx0 : 0;
+  }
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + c);
   const bool relu_in = p.flags & SG_RELU_IN, accum = p.flags & SG_ACCUM, relu_out = p.flags & SG_RELU_OUT;
-  // cq divides the 256-thread block, so a thread keeps its channel group and walks pixels m0, m0 + step, ...: the pixel
-  // cursor (b, yg, xg) is decoded once and advanced without divisions
-  const long mstep = gsz / cq;
-  long m = gtid / cq;
-  int b = (int)(m / HW), yg, xg;
-  {
-    const int rem = (int)(m - (long)b * HW);
-    yg = rem / p.Wg;
-    xg = rem - yg * p.Wg;
-  }
-  const int adv_b = (int)(mstep / HW), adv_r = (int)(mstep - (long)adv_b * HW), adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
-  for (; m < M; m += mstep) {
-    float4 o = bv;
+  const int total_rows = p.Bn * p.Hg, stage_n = win.nrows * win.span;
+  for (int row = blockIdx.x; row < total_rows; row += gridDim.x) {
+    const int b = row / p.Hg, yg = row - b * p.Hg;
+    __syncthreads();
+    for (int e = threadIdx.x; e < stage_n; e += 256) {
+      const int r = e / win.span, xx = e - r * win.span;
+      const int iy = yg + win.dy0 + r, ix = xx + win.dx0;
+      float v = 0.f;
+      if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) v = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
+      rows[e] = relu_in ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
+    for (int x = pl; x < p.Wg; x += lanes) {
+      float4 o = bv;
 #pragma unroll
-    for (int t = 0; t < SG_MAX_TAPS; ++t) {
-      if (t < p.ntaps) {
-        const int iy = yg + p.taps[t].dy, ix = xg + p.taps[t].dx;
-        float a = 0.f;
-        if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
-        if (relu_in) a = fmaxf(a, 0.f);
-        o.x += a * wv[t].x; o.y += a * wv[t].y; o.z += a * wv[t].z; o.w += a * wv[t].w;
+      for (int t = 0; t < SG_MAX_TAPS; ++t) {
+        if (t < p.ntaps) {
+          const float a = rows[toff[t] + x];
+          o.x += a * wv[t].x; o.y += a * wv[t].y; o.z += a * wv[t].z; o.w += a * wv[t].w;
+        }
       }
+      const size_t m = (size_t)row * p.Wg + x;
+      float* op = p.out + m * p.C + c;
+      if (p.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(p.mask + m * p.C + c);
+        if (mk.x <= 0.f) o.x = 0.f;
+        if (mk.y <= 0.f) o.y = 0.f;
+        if (mk.z <= 0.f) o.z = 0.f;
+        if (mk.w <= 0.f) o.w = 0.f;
+      }
+      if (accum) {
+        const float4 pv = *reinterpret_cast<const float4*>(op);
+        o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+      }
+      if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(op) = o;
     }
-    float* op = p.out + (size_t)m * p.C + c;
-    if (p.mask) {
-      const float4 mk = *reinterpret_cast<const float4*>(p.mask + (size_t)m * p.C + c);
-      if (mk.x <= 0.f) o.x = 0.f;
-      if (mk.y <= 0.f) o.y = 0.f;
-      if (mk.z <= 0.f) o.z = 0.f;
-      if (mk.w <= 0.f) o.w = 0.f;
-    }
-    if (accum) {
-      const float4 pv = *reinterpret_cast<const float4*>(op);
-      o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
-    }
-    if (relu_out) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    *reinterpret_cast<float4*>(op) = o;
-    xg += adv_x;
-    const int cx = xg >= p.Wg ? 1 : 0;
-    xg -= cx * p.Wg;
-    yg += adv_y + cx;
-    const int cy = yg >= p.Hg ? 1 : 0;
-    yg -= cy * p.Hg;
-    b += adv_b + cy;
   }
 }
 
+// (Round 2 measured two LDS-staged scatter forms that read the wide tensor once -- 16 lanes per pixel with a butterfly sum per
+//  tap, and lane = pixel over a transposed LDS tile -- at 0.54 and 0.87 TB/s against this kernel's 1.2: the barriers and the
+//  short per-row phases cost more than the 9x re-reads, which come from L2.  Kept as it was.)
 // contract: out[m] = sum_t sum_c aC[pix(m)+tap_t, c] * w_t[c] + bias[0]   (out has ONE channel)
 // 16 lanes per pixel, float4 of channels per lane, 4-step shuffle reduction.
 __global__ __launch_bounds__(256) void sg_thin_contract_kernel(const SgThinArgs p) {
@@ -606,9 +617,13 @@ static int launch_thin(const SgThinArgs& a, bool expand, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   if (M <= 0) return SG_OK;
   if (a.C & 3) return SG_ERR_ARG;
+  const SgThinWin win = sg_thin_window(a);
   if (expand) {
     if (256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(sg_thin_expand_kernel, dim3(sg_grid_for(M * (a.C >> 2), 256)), dim3(256), 0, s, a);
+    const size_t lds = sizeof(float) * (size_t)win.nrows * win.span;
+    if (lds > 60 * 1024) return SG_ERR_UNSUPPORTED;
+    const long rows = (long)a.Bn * a.Hg;
+    hipLaunchKernelGGL(sg_thin_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), lds, s, a, win);
   } else {
     hipLaunchKernelGGL(sg_thin_contract_kernel, dim3(sg_grid_for(M * 16, 256)), dim3(256), 0, s, a);
   }

@@ -322,72 +322,73 @@ int sg_launch_wgrad(const SgWgradArgs& a_in, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // thin weight-grad: dW_t[c] += sum_m p1[pix(m)+tap_t] * Q[m, c]   (p1 has ONE channel)
+// A workgroup owns a run of output rows.  Per row the one-channel rows it needs are staged in LDS (zero outside the image, ReLU
+// applied), then thread (channel group, pixel lane) streams the row of Q with 16-byte loads: per float4 of Q a few LDS
+// broadcasts and FMAs, no dependent global load, no bounds check (round 1: 1.2 TB/s of Q).  Ends with one LDS tree and one
+// float atomic per (tap, channel) and workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, int pix_per_block) {
+__global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, int rows_per_block, int dy0, int nrows, int dx0, int span) {
+  extern __shared__ float rows[];      // [nrows][span]
   __shared__ float4 red[256];
   const int cqn = p.C >> 2;            // float4 groups per pixel (divides 256)
   const int lanes = 256 / cqn;         // pixels in flight per block
   const int cq = threadIdx.x % cqn, pl = threadIdx.x / cqn;
-  const long M = (long)p.Bn * p.Hg * p.Wg;
-  const int HW = p.Hg * p.Wg;
-  const long m_begin = (long)blockIdx.x * pix_per_block;
-  const long m_end = min(M, m_begin + pix_per_block);
+  const int total_rows = p.Bn * p.Hg;
+  const int row_begin = blockIdx.x * rows_per_block;
+  const int row_end = row_begin + rows_per_block < total_rows ? row_begin + rows_per_block : total_rows;
   const bool relu_in = p.flags & SG_RELU_IN;
   const bool relu_q = p.flags & 16;    // internal: ReLU on the C-channel operand (Cout == 1 weight-grad)
   float4 acc[SG_MAX_TAPS];
+  int toff[SG_MAX_TAPS];
 #pragma unroll
-  for (int t = 0; t < SG_MAX_TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the C-channel operand (bias gradient when it is dy)
-  // U pixels per thread and iteration (U independent 16-byte loads in flight: the sweep is latency-bound otherwise), each
-  // with its own pixel cursor (b, yg, xg), decoded once and advanced by U * lanes pixels without divisions
-  constexpr int U = 4;
-  int cb[U], cy[U], cx[U];
-#pragma unroll
-  for (int j = 0; j < U; ++j) {
-    const long mj = m_begin + pl + (long)j * lanes;
-    cb[j] = (int)(mj / HW);
-    const int rem = (int)(mj - (long)cb[j] * HW);
-    cy[j] = rem / p.Wg;
-    cx[j] = rem - cy[j] * p.Wg;
+  for (int t = 0; t < SG_MAX_TAPS; ++t) {
+    acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    toff[t] = t < p.ntaps ? (p.taps[t].dy - dy0) * span + p.taps[t].dx - dx0 : 0;
   }
-  const int step = U * lanes;
-  const int adv_b = step / HW, adv_r = step - adv_b * HW, adv_y = adv_r / p.Wg, adv_x = adv_r - adv_y * p.Wg;
-  for (long m = m_begin + pl; m < m_end; m += step) {
-    float4 q[U];
-    bool live[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const long mj = m + (long)j * lanes;
-      live[j] = mj < m_end;
-      q[j] = live[j] ? *reinterpret_cast<const float4*>(p.w + (size_t)mj * p.C + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qsum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the C-channel operand (bias gradient when it is dy)
+  constexpr int RB = 8;                // output rows per staging round (inside one image): few barriers, long load streams
+  for (int row0 = row_begin; row0 < row_end;) {
+    const int b = row0 / p.Hg, yg0 = row0 - b * p.Hg;
+    int nb = row_end - row0 < RB ? row_end - row0 : RB;
+    nb = p.Hg - yg0 < nb ? p.Hg - yg0 : nb;
+    const int stage_n = (nb + nrows - 1) * span;
+    __syncthreads();
+    for (int e = threadIdx.x; e < stage_n; e += 256) {
+      const int r = e / span, xx = e - r * span;
+      const int iy = yg0 + dy0 + r, ix = xx + dx0;
+      float v = 0.f;
+      if (iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) v = p.a[((size_t)b * p.Ha + iy) * p.Wa + ix];
+      rows[e] = relu_in ? fmaxf(v, 0.f) : v;
     }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-      if (p.qscale) { const float sc = live[j] ? p.qscale[cb[j]] : 0.f; q[j].x *= sc; q[j].y *= sc; q[j].z *= sc; q[j].w *= sc; }
-      if (relu_q) { q[j].x = fmaxf(q[j].x, 0.f); q[j].y = fmaxf(q[j].y, 0.f); q[j].z = fmaxf(q[j].z, 0.f); q[j].w = fmaxf(q[j].w, 0.f); }
-      qsum.x += q[j].x; qsum.y += q[j].y; qsum.z += q[j].z; qsum.w += q[j].w;
+    __syncthreads();
+    const float sc = p.qscale ? p.qscale[b] : 1.f;
+    const float* qblk = p.w + (size_t)row0 * p.Wg * p.C + 4 * cq;
+    const int npix = nb * p.Wg;
+    int yl = 0, x = pl;                  // (yl, x) of pixel idx, advanced without divisions (lanes <= 64 <= Wg is not required: while)
+    while (x >= p.Wg) { x -= p.Wg; ++yl; }
+#pragma unroll 4
+    for (int idx = pl; idx < npix; idx += lanes) {
+      float4 q = *reinterpret_cast<const float4*>(qblk + (size_t)idx * p.C);
+      q.x *= sc; q.y *= sc; q.z *= sc; q.w *= sc;
+      if (relu_q) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+      qsum.x += q.x; qsum.y += q.y; qsum.z += q.z; qsum.w += q.w;
+      const int base = yl * span + x;
 #pragma unroll
       for (int t = 0; t < SG_MAX_TAPS; ++t) {
         if (t < p.ntaps) {
-          const int iy = cy[j] + p.taps[t].dy, ix = cx[j] + p.taps[t].dx;
-          float a = 0.f;
-          if (live[j] && iy >= 0 && iy < p.Ha && ix >= 0 && ix < p.Wa) a = p.a[((size_t)cb[j] * p.Ha + iy) * p.Wa + ix];
-          if (relu_in) a = fmaxf(a, 0.f);
-          acc[t].x += a * q[j].x; acc[t].y += a * q[j].y; acc[t].z += a * q[j].z; acc[t].w += a * q[j].w;
+          const float a = rows[toff[t] + base];
+          acc[t].x += a * q.x; acc[t].y += a * q.y; acc[t].z += a * q.z; acc[t].w += a * q.w;
         }
       }
-      cx[j] += adv_x;
-      const int wx = cx[j] >= p.Wg ? 1 : 0;
-      cx[j] -= wx * p.Wg;
-      cy[j] += adv_y + wx;
-      const int wy = cy[j] >= p.Hg ? 1 : 0;
-      cy[j] -= wy * p.Hg;
-      cb[j] += adv_b + wy;
+      x += lanes;
+      while (x >= p.Wg) { x -= p.Wg; ++yl; }
     }
+    row0 += nb;
   }
 #pragma unroll
   for (int t = 0; t < SG_MAX_TAPS; ++t) {
     if (t >= p.ntaps) continue;   // block-uniform
+    __syncthreads();
     red[threadIdx.x] = acc[t];
     __syncthreads();
     for (int s = lanes >> 1; s > 0; s >>= 1) {
@@ -404,10 +405,10 @@ __global__ __launch_bounds__(256) void sg_thin_wgrad_kernel(const SgThinArgs p, 
       float* d = p.out + p.taps[t].w_off + 4 * cq;
       atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
     }
-    __syncthreads();
   }
 
   if (p.bias) {        // block-uniform: dbias[c] += column sums
+    __syncthreads();
     red[threadIdx.x] = qsum;
     __syncthreads();
     for (int s = lanes >> 1; s > 0; s >>= 1) {
@@ -433,15 +434,22 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   if (M <= 0) return SG_OK;
   if ((a.C & 3) || 256 % (a.C >> 2)) return SG_ERR_UNSUPPORTED;
-  // 256..1024 workgroups of >= 128 pixels: each ends in one float atomic per (tap, channel), and same-address atomics
-  // serialise (~90 ns each), so the adder count per address is what bounds this kernel on small inputs while large
-  // inputs want the parallelism
-  long nb = (M + 639) / 640;                      // 256 workgroups at the 8-way shard size, 1024 at bs 128 (both measured)
-  nb = nb < 256 ? 256 : (nb > 1024 ? 1024 : nb);
-  int ppb = (int)((M + nb - 1) / nb);
-  ppb = ppb < 128 ? 128 : ppb;
-  const int grid = sg_cdiv(M, ppb);
-  hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), 0, s, a, ppb);
+  int dy0 = a.taps[0].dy, dy1 = dy0, dx0 = a.taps[0].dx, dx1 = dx0;
+  for (int t = 1; t < a.ntaps; ++t) {
+    dy0 = a.taps[t].dy < dy0 ? a.taps[t].dy : dy0; dy1 = a.taps[t].dy > dy1 ? a.taps[t].dy : dy1;
+    dx0 = a.taps[t].dx < dx0 ? a.taps[t].dx : dx0; dx1 = a.taps[t].dx > dx1 ? a.taps[t].dx : dx1;
+  }
+  const int nrows = dy1 - dy0 + 1, span = a.Wg + dx1 - dx0;
+  const size_t lds = sizeof(float) * (size_t)(8 + nrows - 1) * span;      // RB = 8 output rows per staging round
+  if (lds > 56 * 1024) return SG_ERR_UNSUPPORTED;
+  // 256..512 workgroups of whole rows: each ends in one float atomic per (tap, channel), and same-address atomics serialise
+  // (~90 ns each), so the adder count per address bounds this kernel on small inputs while large inputs want the parallelism
+  const long total_rows = (long)a.Bn * a.Hg;
+  long nb = total_rows < 512 ? total_rows : 512;
+  if (nb < 1) nb = 1;
+  const int rpb = (int)((total_rows + nb - 1) / nb);
+  const int grid = (int)((total_rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), lds, s, a, rpb, dy0, nrows, dx0, span);
   return sg_launch_status();
 }
 

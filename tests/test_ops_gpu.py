@@ -46,6 +46,12 @@ CONV_CASES = [
     (2, 8, 8, 1, 64, 1, True),        # thin 1x1 shortcut
     (2, 8, 8, 64, 1, 3, True),        # thin contract (generator head)
     (5, 7, 5, 16, 32, 3, True),       # odd spatial dims, M not a multiple of anything
+    (3, 9, 21, 1, 64, 3, True),       # thin kernels (round 2: LDS-staged rows / strips): odd dims, a ragged last strip of rows
+    (3, 9, 21, 64, 1, 3, True),
+    (2, 6, 9, 1, 64, 2, False),       # ... VALID 2x2 (tap window 0..1)
+    (2, 6, 9, 64, 1, 2, False),
+    (1, 32, 368, 64, 1, 3, True),     # ... the widest bucket (L = 23): the contraction's strip shrinks to fit its LDS planes
+    (1, 32, 368, 1, 64, 3, True),
     (3, 4, 9, 256, 256, 3, True),     # 256-channel tiles: ragged last pixel tile, sample boundary inside a tile
     (2, 5, 7, 256, 512, 1, True),     # ... 1x1, two Cout tiles
 ]

@@ -494,7 +494,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
                  _flags(relu_in), _stream())
         return
     with _timed("wgrad", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
-                ("wgrad", B, H, W, Cin, Cout, kh)):
+                ("wgrad", B, H, W, Cin, Cout, kh), (x, dy)):
         call("sg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, kh, kw, int(same),
              _flags(relu_in) | (MMA_BF16 if _low() else 0), _stream())
 

@@ -214,6 +214,7 @@ def main():
     timing_in_region = timer is not None and world == 1
     ops.PROFILER = timer if timing_in_region else None
     fence()
+    calls_before = getattr(reducer, "calls", 0)          # collectives of the warm-up steps
     t0 = time.perf_counter()
     outs = []
     host_enqueue = 0.0                                            # host time spent queuing the steps (no device waits in there)
@@ -226,6 +227,7 @@ def main():
     fence()
     tuple(outs[-1])
     elapsed = time.perf_counter() - t0
+    calls_timed = getattr(reducer, "calls", 0) - calls_before      # collectives inside the timed region (before any extra timing steps)
     ops.PROFILER = None
     if world > 1:                      # the measurement proper is complete here: MAX over ranks first, extras afterwards
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -279,7 +281,7 @@ def main():
         line["config"]["shared_backward"] = True
         line["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1
         line["backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"
-        line["collectives_per_step"] = getattr(reducer, "calls", 0) / max(1, args.warmup + args.steps) if world > 1 else 0
+        line["collectives_per_step"] = calls_timed / max(1, args.steps) if world > 1 else 0
         if timer is not None:
             try:
                 ks = timer.summary()

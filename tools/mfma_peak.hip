@@ -258,6 +258,37 @@ __global__ __launch_bounds__(512, 2) void k_loop(const float* src, float* sink, 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc_out += acc[i][r];
   }
+  if (MODE == 14) {   // bf16 16x16x32 with the conv loop's LDS traffic: 12 ds_read_b128 per 32 MFMAs (the same bytes per FLOP as
+    // six reads per eight 32x32x16 MFMAs), single fragment set read in front of the step, barrier per 2 steps (= 64 k)
+    __shared__ float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = s[i & 15];
+    __syncthreads();
+    f32x4 acc[32];
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i af[8], bf[4];
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + 16u * (threadIdx.x & 63);
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 4; ++e) af[i][e] = __float_as_int(s[(i + e) & 15]) & 0x3fff3fff;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) bf[i][e] = __float_as_int(s[(9 + i + e) & 15]) & 0x3fff3fff;
+#define RD12(o) do { RDQ(af[0], (o)); RDQ(af[1], (o) + 1024); RDQ(af[2], (o) + 2048); RDQ(af[3], (o) + 3072); RDQ(af[4], (o) + 4096); RDQ(af[5], (o) + 5120); \
+    RDQ(af[6], (o) + 6144); RDQ(af[7], (o) + 7168); RDQ(bf[0], (o) + 8192); RDQ(bf[1], (o) + 9216); RDQ(bf[2], (o) + 10240); RDQ(bf[3], (o) + 11264); } while (0)
+    auto mma16 = [&]() {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i * 4 + j], 0, 0, 0);
+    };
+    t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters / 2; ++it) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB(); mma16(); SB(); RD12(12288);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB(); mma16(); SB();
+      __builtin_amdgcn_s_barrier();
+      RD12(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc_out += acc[i][r];
+  }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   sink[blockIdx.x * 512 + threadIdx.x] = acc_out;
   if (lane == 0 && (threadIdx.x >> 6) == 0) {
@@ -330,5 +361,6 @@ int main() {
   run<13>("f32 ... in-front reads, 8 max() batched per step", 2.0 * 32 * 32 * 2, 8, src, sink, stamps);
   run<9>("bf16 32x32x16 + 6 ds_read_b128 in front", 2.0 * 32 * 32 * 16, 8, src, sink, stamps);
   run<10>("bf16 32x32x16 + 6 ds_read_b128 spread", 2.0 * 32 * 32 * 16, 8, src, sink, stamps);
+  run<14>("bf16 16x16x32 + 12 ds_read_b128 per 32 MFMAs (one fragment set)", 2.0 * 16 * 16 * 32, 32, src, sink, stamps);
   return 0;
 }

@@ -114,60 +114,53 @@ def dry_run(args):
         print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "rccl_ranks": ranks, "backend": backend, "allreduce_of_ones": got}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="GLOBAL batch (fixed as N grows)")
-    ap.add_argument("--L", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-steps", type=int, default=2, help="N > 1 only: extra steps after the timed region for the per-kernel HIP-event timing")
-    ap.add_argument("--conv-dtype", default="f32", choices=["f32", "bf16", "fp8"],
-                    help="matrix-core operand type of the convolutions: f32 = the headline config c2; bf16 = config c3 (run it with --batch 256); "
-                         "fp8 = config c5, first slice (fp8 forward / data-grad, bf16 weight-grad and recognizer; --batch 512 --balance)")
-    ap.add_argument("--balance", action="store_true", help="apply_gradient_balance = 1 (config c5)")
-    ap.add_argument("--bucketed", action="store_true",
-                    help="config c4: one (L_r, L_f) pair per step drawn U{4..23}^2 from a stream shared by all ranks (bucket_size 23)")
-    ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
-    ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
-    ap.add_argument("--dry-run", action="store_true", help="rendezvous + one all-reduce only, no GPU work (launcher rehearsal on CPU)")
-    args = ap.parse_args()
+WORKLOADS = {
+    "f32": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1",
+    "bf16": "c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, bf16 operand copies in HBM), hinge, disc_iters=1",
+    "fp8": "c5: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp8 convs of G/D/S (e4m3 forward / data-grad operands, e4m3 x e5m2 weight-grads, >= 128 channels), bf16 recognizer + CTC, hinge",
+}
+DTYPE_NAME = {"f32": "f32", "bf16": "bf16", "fp8": "fp8 (e4m3 / e5m2) + bf16"}
+# dense matrix-core peaks of MI355X_MICROARCH.md's chip table, per kernel family
+PEAK_TF = {"f32": PEAK_FP32_MFMA_TF, "bf16": 2500.0, "fp8": 5000.0}
 
-    # N > 1 from a bare shell: start the ranks (nothing in this process has touched the GPU yet)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args, sys.argv[1:])
-    if args.dry_run:
-        return dry_run(args)
 
-    from scrabble_gan_amd import data_utils as DU, dist as sdist, net_architecture as NA, net_loss, ops, optimizers
+def _git_commit_of(path):
+    """Short hash and date of the last commit that touched `path` ('uncommitted' when git has none / is absent)."""
+    import subprocess
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", path], capture_output=True, text=True, timeout=10)
+        return r.stdout.strip() or "uncommitted"
+    except Exception:  # noqa: BLE001
+        return "unknown"
+
+
+def committed_traffic(kernel, conv_dtype, per_gpu_batch):
+    """HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py; counters need
+    their own rocprofv3 runs, so the figure is read back, not measured in this process) -> (bytes, source string carrying
+    the profile file's commit and date, so a stale figure is visible as such)."""
+    import glob
+    tag = "%s%s_traffic_bs%d.json" % (kernel, {"f32": "", "bf16": "_bf16", "fp8": "_fp8"}[conv_dtype], per_gpu_batch)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + tag)))
+    if not files:
+        return None, None
+    tj = json.load(open(files[-1]))
+    rel = "profiles/" + os.path.basename(files[-1])
+    return tj["traffic_bytes_per_launch"], "%s @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % (
+        rel, _git_commit_of(rel))
+
+
+def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev, world, bucketed=False, sync_every_step=False,
+            kernel_timing=True, shape_table=None, hbm_families=True):
+    """Build the four networks, run `warmup` + `steps` train_steps of one configuration with the inputs resident in HBM, and
+    return everything measured: wall time of the timed region (MAX over ranks), HIP-event summaries of the kernel families.
+    The models and every per-step buffer are released before returning."""
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
     from scrabble_gan_amd.main import build_models
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE "
-                         "and let bench.py start its own ranks" % (args.gpus, world, args.gpus))
-    # SG_DIST_BACKEND=gloo SG_FORCE_DEVICE=0 rehearse the multi-rank path with several ranks on ONE GPU (RCCL needs
-    # one device per rank); the driver's runs use the defaults: nccl, one GPU per rank.
-    backend = os.environ.get("SG_DIST_BACKEND", "nccl")
-    local_rank = int(os.environ.get("SG_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    if backend != "nccl":
-        torch.cuda.set_device(local_rank)
-    reducer = sdist.init_from_env(backend)
-    rank = getattr(reducer, "rank", 0)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas
-    ops.set_conv_dtype(args.conv_dtype)
-    bf16 = args.conv_dtype in ("bf16", "fp8")
-    peak_tf = 2500.0 if bf16 else PEAK_FP32_MFMA_TF            # dense peaks of MI355X_MICROARCH.md's chip table
-
+    ops.set_conv_dtype(conv_dtype)
     in_dim = (32, 160, 1)
+    NA.configure(device=dev, seed=0, reducer=reducer)         # same seed on every rank -> identical replicas
     G, D, R, S, gan = build_models(in_dim, 128, (32, 8192), None, "B3", "B1", 52, None)
     opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
-
-    B, L = args.batch, args.L
     images, labels, my_imgs = DU.synthetic_batch(B, L, in_dim, 52, seed=0)
     words = DU.synthetic_random_words(max(10, L), 1000, 52, seed=0)
     random.seed(0)
@@ -179,7 +172,7 @@ def main():
     # sync="lazy": the 16 scalars of a step come back by an asynchronous copy and are read after the next step has
     # been queued (as scrabble_gan_amd.data_utils.train does); every step's values are read and checked below.
     pools = None
-    if args.bucketed:          # variable-width words: inputs of every bucket resident in HBM, the per-step pair from a shared stream
+    if bucketed:          # variable-width words: inputs of every bucket resident in HBM, the per-step pair from a shared stream
         words23 = DU.synthetic_random_words(23, 1000, 52, seed=0)
         pools = {}
         for Lb in range(4, 24):
@@ -187,17 +180,17 @@ def main():
             fk = np.array([random.choice(words23[Lb - 1]) for _ in range(B)], np.int32)
             pools[Lb] = (torch.from_numpy(im).to(dev), torch.from_numpy(lb).to(dev), torch.from_numpy(fk).to(dev))
         pair_rng = np.random.default_rng(7)
-        pairs = [tuple(int(v) for v in pair_rng.integers(4, 24, 2)) for _ in range(args.warmup + args.steps + args.timing_steps)]
+        pairs = [tuple(int(v) for v in pair_rng.integers(4, 24, 2)) for _ in range(warmup + steps + 2 * timing_steps)]
 
     def step(i):
         if pools is not None:
             L_r, L_f = pairs[i % len(pairs)]
-            return DU.train_step(0, i, args.steps, pools[L_r][0], pools[L_r][1], D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d,
+            return DU.train_step(0, i, steps, pools[L_r][0], pools[L_r][1], D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d,
                                  B, 128, net_loss.hinge, 1, 0, words, 23, "", fake_labels=pools[L_f][2], verbose=False,
-                                 sync=True if args.sync_every_step else "lazy")
-        return DU.train_step(0, i, args.steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
-                             net_loss.hinge, 1, int(args.balance), words, max(10, L), "", fake_labels=fake_d, verbose=False,
-                             sync=True if args.sync_every_step else "lazy")
+                                 sync=True if sync_every_step else "lazy")
+        return DU.train_step(0, i, steps, images_d, labels_d, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d, B, 128,
+                             net_loss.hinge, 1, int(balance), words, max(10, L), "", fake_labels=fake_d, verbose=False,
+                             sync=True if sync_every_step else "lazy")
 
     def fence():
         torch.cuda.synchronize()
@@ -205,12 +198,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i - args.warmup)            # negative indices: the warm-up draws its own pairs in --bucketed mode
+    for i in range(warmup):
+        step(i - warmup)            # negative indices: the warm-up draws its own pairs in --bucketed mode
     # Kernel timing (HIP events around every MFMA conv launch, on the launch stream) runs inside the timed region at
     # N = 1.  At N > 1 the per-GPU batch is small enough for the event records to cost a few percent, so there the
     # timed region runs bare and the roofline figures come from --timing-steps extra steps right after it.
-    timer = None if args.no_kernel_timing else ops.KernelTimer(only=("igemm", "wgrad"))      # the MFMA conv kernels (+ their thin variants)
+    timer = ops.KernelTimer(only=("igemm", "wgrad")) if kernel_timing else None      # the MFMA conv kernels (+ their thin variants)
     timing_in_region = timer is not None and world == 1
     ops.PROFILER = timer if timing_in_region else None
     fence()
@@ -218,7 +211,7 @@ def main():
     t0 = time.perf_counter()
     outs = []
     host_enqueue = 0.0                                            # host time spent queuing the steps (no device waits in there)
-    for i in range(args.steps):
+    for i in range(steps):
         t_q = time.perf_counter()
         outs.append(step(i))
         host_enqueue += time.perf_counter() - t_q
@@ -234,28 +227,191 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     assert all(np.isfinite(float(v)) for o in outs for v in o), outs
-    timed_steps = args.steps
+    timed_steps = steps
     if timer is not None and not timing_in_region:
         ops.PROFILER = timer
-        extra = [step(args.steps + i) for i in range(args.timing_steps)]
+        extra = [step(steps + i) for i in range(timing_steps)]
         fence()
         ops.PROFILER = None
-        timed_steps = args.timing_steps
+        timed_steps = timing_steps
         for o in extra:
             tuple(o)
     # The memory-bound kernel families (BN, pools, Adam, filter bank, elementwise, attention) are timed in extra steps
     # AFTER the timed region, so that their ~1 000 event records per step never touch the headline number.
     hbm_timer = None
-    if timer is not None and args.timing_steps > 0:
+    if timer is not None and timing_steps > 0 and hbm_families:
         hbm_timer = ops.KernelTimer()
         ops.PROFILER = hbm_timer
-        extra = [step(args.steps + args.timing_steps + i) for i in range(args.timing_steps)]
+        extra = [step(steps + timing_steps + i) for i in range(timing_steps)]
         fence()
         ops.PROFILER = None
         for o in extra:
             tuple(o)
+    res = {"elapsed": elapsed, "steps": steps, "B": B, "L": L, "host_enqueue": host_enqueue, "calls_timed": calls_timed,
+           "timed_steps": timed_steps, "timing_in_region": timing_in_region, "ks": None, "hs": None, "hroof": None, "error": None}
+    if timer is not None:
+        try:
+            res["ks"] = timer.summary()
+            if hbm_timer is not None:
+                res["hs"], res["hroof"] = hbm_timer.summary(), dict(hbm_timer.roof)
+            if shape_table:
+                with open(shape_table, "w") as f:
+                    f.write("# per-shape MFMA conv launches inside train_step, per-GPU batch %d, %d steps (HIP events on the launch stream)\n" % (B // world, timed_steps))
+                    f.write("%-9s %-12s %5s %4s %4s %5s %5s %2s | %4s %9s %8s\n" % ("family", "kind", "B", "H", "W", "Cin", "Cout", "k", "n", "ms/step", "TFLOP/s"))
+                    for fam, tag, n, ms_, tf in timer.by_shape():
+                        f.write("%-9s %-12s %5d %4d %4d %5d %5d %2d | %4d %9.3f %8.1f\n" % ((fam,) + tuple(tag) + (n // timed_steps, ms_ / timed_steps, tf)))
+        except Exception as e:  # noqa: BLE001  (the headline numbers must still be printed)
+            res["error"] = repr(e)
+    # release the models, optimizer slots, saved contexts and operand copies before the next configuration is built
+    del G, D, R, S, gan, opts, outs, images_d, my_d, labels_d, fake_d, pools
+    ops.new_step()
+    ops.weights_changed()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_of(res, conv_dtype, world):
+    """`roofline` (the dominant kernel family of the configuration) + `kernels` (every MFMA conv family) + `hbm_kernels`."""
+    ks, timed_steps = res["ks"], res["timed_steps"]
+    out = {}
+    if ks is None:
+        if res["error"]:
+            out["roofline_error"] = res["error"]
+        return out
+    # fp8 mode: the e4m3 / e5m2 launches are their own families ('igemm_fp8', 'wgrad_fp8', peak 5 PF); the launches that stay
+    # bf16 there (64-channel layers, recognizer, transposed convs) keep 'igemm' / 'wgrad' against the bf16 peak (ADVICE r2)
+    def peak_of(fam):
+        if fam.endswith("_fp8"):
+            return PEAK_TF["fp8"]
+        return PEAK_TF["f32"] if conv_dtype == "f32" else PEAK_TF["bf16"]
+    dom = "igemm_fp8" if (conv_dtype == "fp8" and "igemm_fp8" in ks) else "igemm"
+    ig = ks.get(dom, {"tflops": 0.0, "launches": 0, "ms": 0.0})
+    try:
+        traffic, traffic_src = committed_traffic("igemm", conv_dtype, res["B"] // world)
+    except Exception:  # noqa: BLE001
+        traffic, traffic_src = None, None
+    kernel_name = {"f32": "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)",
+                   "bf16": "sg_igemm_bf16v2_kernel<BN, 2, RELU> / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; <= 32-filter convs stay fp32)",
+                   "fp8": "sg_igemm_bf16v2_kernel<256, 1, false> (conv fwd + data-grad of the >= 128-channel layers, v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 operands)"}[conv_dtype]
+    out["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_of(dom), "unit": "TFLOP/s",
+                       "frac": ig["tflops"] / peak_of(dom), "traffic": traffic, "traffic_source": traffic_src,
+                       "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
+                       "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
+                       "kernel": kernel_name, "family": dom,
+                       "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
+                       "timed": "inside the timed region" if res["timing_in_region"] else "%d extra steps after the timed region" % timed_steps}
+    out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
+                          "launches_per_step": v["launches"] / timed_steps, "peak_tflops": peak_of(k) if not k.endswith("_thin") else None,
+                          "frac_of_mfma_peak": round(v["tflops"] / peak_of(k), 4) if not k.endswith("_thin") else None}
+                      for k, v in ks.items()}
+    if "wgrad" in out["kernels"]:
+        try:
+            wt, wsrc = committed_traffic("wgrad", conv_dtype, res["B"] // world)
+        except Exception:  # noqa: BLE001
+            wt, wsrc = None, None
+        out["kernels"]["wgrad"].update({"traffic": wt, "traffic_source": wsrc})
+    if res["hs"] is not None:
+        # memory-bound families: algorithmic bytes (every operand once + every result once) / HIP-event time,
+        # against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy reaches)
+        out["hbm_kernels"] = {}
+        for k, v in sorted(res["hs"].items(), key=lambda kv: -kv[1]["ms"]):
+            roof = res["hroof"].get(k, "hbm")
+            if roof == "mfma" or v["ms"] <= 0:
+                continue
+            nst = max(1, res["hbm_steps"]) if "hbm_steps" in res else 1
+            gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            ent = {"bound": roof, "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] / nst,
+                   "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
+            if v["flops"]:
+                ent["tflops"] = round(v["tflops"], 2)
+            out["hbm_kernels"][k] = ent
+    if res["error"]:
+        out["roofline_error"] = res["error"]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL batch (fixed as N grows); default 128")
+    ap.add_argument("--L", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-steps", type=int, default=2, help="extra steps after the timed region for the per-kernel HIP-event timing of the memory-bound families (and, at N > 1, of the conv kernels)")
+    ap.add_argument("--conv-dtype", default=None, choices=["f32", "bf16", "fp8"],
+                    help="matrix-core operand type of the convolutions: f32 = the headline config c2 (default); bf16 = config c3 (run it with --batch 256); "
+                         "fp8 = config c5 (fp8 forward / data-grad / weight-grad of the >= 128-channel convs of G/D/S, bf16 recognizer; --batch 512 --balance)")
+    ap.add_argument("--balance", action="store_true", help="apply_gradient_balance = 1 (config c5)")
+    ap.add_argument("--bucketed", action="store_true",
+                    help="config c4: one (L_r, L_f) pair per step drawn U{4..23}^2 from a stream shared by all ranks (bucket_size 23)")
+    ap.add_argument("--sync-every-step", action="store_true", help="read the 16 scalars back before queuing the next step")
+    ap.add_argument("--shape-table", default=None, help="write the per-shape time / TFLOP/s table of the MFMA conv kernels here")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="the default N = 1 invocation also measures configs c3 (bf16, bs 256) and c5 (fp8, bs 512, balancing) after the "
+                         "headline's timed region and reports them under \"configs\"; this flag skips them")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + one all-reduce only, no GPU work (launcher rehearsal on CPU)")
+    args = ap.parse_args()
+    plain_invocation = args.conv_dtype is None and args.batch is None and not args.bucketed and not args.balance and args.L == 10
+    if args.conv_dtype is None:
+        args.conv_dtype = "f32"
+    if args.batch is None:
+        args.batch = 128
+
+    # N > 1 from a bare shell: start the ranks (nothing in this process has touched the GPU yet)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
+    if args.dry_run:
+        return dry_run(args)
+
+    from scrabble_gan_amd import dist as sdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or unset WORLD_SIZE "
+                         "and let bench.py start its own ranks" % (args.gpus, world, args.gpus))
+    # SG_DIST_BACKEND=gloo SG_FORCE_DEVICE=0 rehearse the multi-rank path with several ranks on ONE GPU (RCCL needs
+    # one device per rank); the driver's runs use the defaults: nccl, one GPU per rank.
+    backend = os.environ.get("SG_DIST_BACKEND", "nccl")
+    local_rank = int(os.environ.get("SG_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if backend != "nccl":
+        torch.cuda.set_device(local_rank)
+    reducer = sdist.init_from_env(backend)
+    rank = getattr(reducer, "rank", 0)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, L = args.batch, args.L
+    res = measure(args.conv_dtype, B, L, args.balance, args.steps, args.warmup, args.timing_steps, reducer, dev, world,
+                  bucketed=args.bucketed, sync_every_step=args.sync_every_step, kernel_timing=not args.no_kernel_timing,
+                  shape_table=args.shape_table if rank == 0 else None)
+    res["hbm_steps"] = args.timing_steps
+
+    # configs c3 and c5 of BASELINE.json in the same (driver-run) invocation: after the headline's timed region and its timing
+    # steps, on freshly built models, each with its own warm-up; single GPU only (the scaling runs time c2 alone)
+    extra = {}
+    if plain_invocation and world == 1 and not args.no_extra_configs and not args.no_kernel_timing:
+        for tag, cd, eb, bal in (("c3", "bf16", 256, False), ("c5", "fp8", 512, True)):
+            try:
+                r = measure(cd, eb, 10, bal, max(3, min(args.steps, 10)), 2, 1, reducer, dev, world, hbm_families=True)
+                r["hbm_steps"] = 1
+                v = eb * r["steps"] / r["elapsed"]
+                ent = {"workload": WORKLOADS[cd] % (eb, 10) + (", gradient balancing on" if bal else ""), "value": v, "unit": "images/s",
+                       "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "steps": r["steps"], "warmup": 2, "dtype": DTYPE_NAME[cd],
+                       "global_batch": eb, "host_enqueue_ms_per_step": r["host_enqueue"] / r["steps"] * 1e3,
+                       "step_algorithmic_tflops": FLOP_PER_IMAGE * v / 1e12}
+                ent.update(roofline_of(r, cd, world))
+                extra[tag] = ent
+            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                extra[tag] = {"error": repr(e)}
+        from scrabble_gan_amd import ops as _ops
+        _ops.set_conv_dtype("f32")
 
     if rank == 0:
+        elapsed = res["elapsed"]
         ms = elapsed / args.steps * 1e3
         value = B * args.steps / elapsed
         try:
@@ -265,15 +421,11 @@ def main():
         line = {
             "metric": metric, "value": value, "unit": "images/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "fp8": "fp8-e4m3 (fwd/dgrad) + bf16"}[args.conv_dtype], "data": "synthetic",
-            "config": {"workload": ("c5 (first slice): synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp8-e4m3 forward / data-grad convs of G/D/S (>= 128 channels), bf16 weight-grad and recognizer, hinge, gradient balancing " + ("on" if args.balance else "off")
-                                    if args.conv_dtype == "fp8" else
-                                    "c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, bf16 operand copies in HBM), hinge, disc_iters=1"
-                                    if bf16 else "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1")
-                                   % (B, L) if not args.bucketed else
+            "vs_baseline": None, "dtype": DTYPE_NAME[args.conv_dtype], "data": "synthetic",
+            "config": {"workload": ((WORKLOADS[args.conv_dtype] % (B, L)) + (", gradient balancing on" if args.balance else "")) if not args.bucketed else
                                    "c4: synthetic random_words 32x(16 L), (L_r, L_f) ~ U{4..23}^2 per step, global bs %d, %s MFMA convs" % (B, args.conv_dtype),
-                                   "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
-            "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
+                       "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
+            "host_enqueue_ms_per_step": res["host_enqueue"] / args.steps * 1e3,
             "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if (L == 10 and not args.bucketed) else None,      # reference-tape accounting
             "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if (L == 10 and not args.bucketed) else None,  # what the kernels actually run
         }
@@ -281,65 +433,10 @@ def main():
         line["config"]["shared_backward"] = True
         line["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1
         line["backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"
-        line["collectives_per_step"] = calls_timed / max(1, args.steps) if world > 1 else 0
-        if timer is not None:
-            try:
-                ks = timer.summary()
-                ig = ks.get("igemm", {"tflops": 0.0, "launches": 0, "ms": 0.0})
-                # HBM-side bytes per launch from the committed PMC passes of this same command (tools/pmc_traffic.py;
-                # counters need their own rocprofv3 runs, so the figure is read back, not measured in this process)
-                def committed_traffic(kernel):
-                    import glob
-                    tag = "%s%s_traffic_bs%d.json" % (kernel, "_bf16" if bf16 else "", B // world)
-                    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + tag)))
-                    if not files:
-                        return None, None
-                    tj = json.load(open(files[-1]))
-                    return tj["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % os.path.basename(files[-1])
-                try:
-                    traffic, traffic_src = committed_traffic("igemm")
-                except Exception:  # noqa: BLE001
-                    traffic, traffic_src = None, None
-                line["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
-                                    "frac": ig["tflops"] / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
-                                    "algorithmic_bytes_per_launch": ig.get("bytes", 0.0) / max(ig["launches"], 1),
-                                    "algorithmic_flop_per_launch": ig.get("flops", 0.0) / max(ig["launches"], 1),
-                                    "kernel": ("sg_igemm_bf16v2_kernel / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16, fp8 32x32x64 in fp8 mode; <= 32-filter convs stay fp32)"
-                                               if bf16 else "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)"),
-                                    "launches_per_step": ig["launches"] / timed_steps, "ms_per_step": ig["ms"] / timed_steps,
-                                    "timed": "inside the timed region" if timing_in_region else "%d extra steps after the timed region" % timed_steps}
-                line["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
-                                       "launches_per_step": v["launches"] / timed_steps} for k, v in ks.items()}
-                if "wgrad" in line["kernels"]:
-                    wg = ks["wgrad"]
-                    try:
-                        wt, wsrc = committed_traffic("wgrad")
-                    except Exception:  # noqa: BLE001
-                        wt, wsrc = None, None
-                    line["kernels"]["wgrad"].update({"frac_of_mfma_peak": round(wg["tflops"] / peak_tf, 4), "traffic": wt, "traffic_source": wsrc})
-                if hbm_timer is not None:
-                    # memory-bound families: algorithmic bytes (every operand once + every result once) / HIP-event time,
-                    # against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy reaches)
-                    hs, nst = hbm_timer.summary(), args.timing_steps
-                    line["hbm_kernels"] = {}
-                    for k, v in sorted(hs.items(), key=lambda kv: -kv[1]["ms"]):
-                        roof = hbm_timer.roof.get(k, "hbm")
-                        if roof == "mfma" or v["ms"] <= 0:
-                            continue
-                        gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-                        ent = {"bound": roof, "ms_per_step": round(v["ms"] / nst, 3), "launches_per_step": v["launches"] / nst,
-                               "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)}
-                        if v["flops"]:
-                            ent["tflops"] = round(v["tflops"], 2)
-                        line["hbm_kernels"][k] = ent
-            except Exception as e:  # noqa: BLE001  (the headline numbers above must still be printed)
-                line["roofline_error"] = repr(e)
-        if timer is not None and args.shape_table:
-            with open(args.shape_table, "w") as f:
-                f.write("# per-shape MFMA conv launches inside train_step, per-GPU batch %d, %d steps (HIP events on the launch stream)\n" % (B // world, timed_steps))
-                f.write("%-7s %-12s %5s %4s %4s %5s %5s %2s | %4s %9s %8s\n" % ("family", "kind", "B", "H", "W", "Cin", "Cout", "k", "n", "ms/step", "TFLOP/s"))
-                for fam, tag, n, ms_, tf in timer.by_shape():
-                    f.write("%-7s %-12s %5d %4d %4d %5d %5d %2d | %4d %9.3f %8.1f\n" % ((fam,) + tuple(tag) + (n // timed_steps, ms_ / timed_steps, tf)))
+        line["collectives_per_step"] = res["calls_timed"] / max(1, args.steps) if world > 1 else 0
+        line.update(roofline_of(res, args.conv_dtype, world))
+        if extra:
+            line["configs"] = extra
         if args.gpus == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -241,9 +241,6 @@ int sg_spectral_norm(const float* w, const float* u, float* out, float* workspac
 long sg_spectral_norm_bwd_workspace_floats(int K, int N);
 int sg_spectral_norm_bwd(const float* w, const float* u, const float* g, float* dw, float* workspace, int K, int N, void* stream);
 
-#ifdef __cplusplus
-}
-#endif
 /* ---- host-pipeline helpers ------------------------------------------------------------------------------
  * sg_normalize_u8: out[i] = (float(u8[i]) - 127.5) / 127.5, the pixel normalisation of load_prepare_data (data_utils.py:82)
  * run on the GPU on bytes that arrived through a pinned staging buffer; bit-identical to the numpy expression; n % 16 == 0.
@@ -266,4 +263,14 @@ int sg_rccl_unique_id(void* id128);                                             
 int sg_rccl_comm_init_rank(void** comm, int nranks, const void* id128, int rank);
 int sg_rccl_comm_destroy(void* comm);
 
+/* ---- reproducibility (the reference's GradientTapes are deterministic on the TF CPU path, data_utils.py:449-468) ----------
+ * sg_set_deterministic(1): process-wide switch.  Every convolution launch (first- and second-generation kernels, fp32 /
+ * bf16 / fp8) then runs ONE workgroup per output tile -- no reduction splits, no float atomics in forward / data-grad --
+ * so a sample's activations do not depend on the batch size it is launched in.  sg_set_deterministic(0) restores the
+ * CU-quantum tail split.  Returns the previous setting. */
+int sg_set_deterministic(int on);
+
+#ifdef __cplusplus
+}
+#endif
 #endif

@@ -353,6 +353,15 @@ __global__ __launch_bounds__(256) void k_relu_inplace(float* x, long n4) {
 
 static int g_split_override = -1;   // tuning/debug: -1 = heuristic, 1 = never split, n > 1 = force n splits
 extern "C" void sg_debug_set_splitk(int n) { g_split_override = n; }
+extern "C" void sg_debug_set_splitk_v2(int n);          // conv_bf16v2.hip: the second-generation kernels' own override
+static int g_deterministic = 0;
+extern "C" int sg_set_deterministic(int on) {
+  const int prev = g_deterministic;
+  g_deterministic = on ? 1 : 0;
+  g_split_override = on ? 1 : -1;
+  sg_debug_set_splitk_v2(on ? 1 : -1);
+  return prev;
+}
 
 template <int BM, int BN, int WM, int WN, int BK = SG_BK, int OCC = 2>
 static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {

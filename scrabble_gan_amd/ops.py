@@ -214,9 +214,9 @@ def packed_filter_fp8(w: torch.Tensor, kind: str):
 
 
 def set_deterministic(on: bool) -> None:
-    """on: force every conv launch to one workgroup per output tile (no split reductions / float atomics in the forward
-    and data-grad kernels).  off: the default CU-quantum tail split."""
-    lib().sg_debug_set_splitk(1 if on else -1)
+    """on: force every conv launch -- first- and second-generation kernels, fp32 / bf16 / fp8 -- to one workgroup per output
+    tile (no split reductions / float atomics in the forward and data-grad kernels).  off: the default CU-quantum tail split."""
+    lib().sg_set_deterministic(1 if on else 0)
 
 
 def weights_changed() -> None:
@@ -397,9 +397,10 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     _touch(out)
     if out is None:
         out = empty(B, Ho, Wo, Cout, like=x)
-    with _timed("igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
+    use8 = _fp8_ok(Cin, Cout, kh, kw, same) and not tanh_out
+    with _timed("igemm_fp8" if use8 else "igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
-        if _fp8_ok(Cin, Cout, kh, kw, same) and not tanh_out:
+        if use8:
             x8, ax = fp8_of(x, relu_in)                       # the operand ReLU is folded into the conversion
             w8, aw = packed_filter_fp8(w, "fwd")
             y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
@@ -435,9 +436,10 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     _touch(out)
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
-    with _timed("igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
+    use8 = _fp8_ok(Cout, Cin, kh, kw, same)
+    with _timed("igemm_fp8" if use8 else "igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
-        if _fp8_ok(Cout, Cin, kh, kw, same):
+        if use8:
             dy8, ady = fp8_of(dy)
             w8, aw = packed_filter_fp8(w, "bwd")
             dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None

@@ -119,12 +119,19 @@ def _r16(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.fixture(params=["f32", "bf16"])
+@pytest.fixture(params=["f32", "bf16", "fp8"])
 def conv_mode(request):
     from scrabble_gan_amd import ops
     ops.set_conv_dtype(request.param)
     yield request.param
     ops.set_conv_dtype("f32")
+
+
+def _q8(t, amax):
+    """e4m3 quantisation exactly as sg_cvt_fp8 / sg_pack_filter_fp8 do it (tests/test_fp8_gpu.py:q8), with the amax of the
+    WHOLE device tensor (the edge samples are quantised with the scale the kernel used for the full batch)."""
+    s = (torch.tensor(448.0) / amax.float().cpu()).float()
+    return (t.float() * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float64)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", GEOM)
@@ -135,6 +142,32 @@ def test_conv_fwd_dgrad_vs_oracle_at_launch_geometry(dev, conv_mode, B, H, W, Ci
     w = torch.randn(k, k, Cin, Cout, device=dev, generator=g) / math.sqrt(k * k * Cin)
     b = torch.randn(Cout, device=dev, generator=g)
     dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    if conv_mode == "fp8":
+        # config c5: the >= 128-channel launches quantise both operands to e4m3 per tensor; the oracle gets the SAME quantised
+        # operands (5e-5: only the fp32 accumulation order differs), VERDICT r2 weak #3.  64-channel / thin rows of GEOM run
+        # exactly as in bf16 mode and are covered there.
+        fwd8, dg8 = ops._fp8_ok(Cin, Cout, k, k, True), ops._fp8_ok(Cout, Cin, k, k, True)
+        if not (fwd8 or dg8):
+            pytest.skip("not an fp8 launch (bf16 path, covered by the bf16 mode)")
+        y = ops.conv2d_fwd(x, w, b, relu_in=True)
+        dx = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+        ax, aw, ad = x.abs().max(), w.abs().max(), dy.abs().max()
+        xe, we, be, dye = _edge(x), w.cpu(), b.double().cpu(), _edge(dy)
+        qw = _q8(we, aw)
+        if fwd8:
+            osc = (ax.cpu() * aw.cpu() * torch.tensor(1.0 / (448.0 * 448.0))).double()
+            _close(_edge(y), O.conv2d(_q8(torch.relu(xe), ax), qw, None) * osc + be, 5e-5, "fp8 y (first/last 2 samples)")
+        else:
+            _close(_edge(y), O.conv2d(_r16(torch.relu(xe)), _r16(we), be), 5e-5, "bf16 y (first/last 2 samples)")
+        xr = xe.clone().requires_grad_(True)
+        if dg8:
+            osd = (ad.cpu() * aw.cpu() * torch.tensor(1.0 / (448.0 * 448.0))).double()
+            O.conv2d(xr, qw, None).backward(_q8(dye, ad))
+            _close(_edge(dx), xr.grad * osd * (xe > 0), 5e-5, "fp8 dx (first/last 2 samples)")
+        else:
+            O.conv2d(xr, _r16(we), None).backward(_r16(dye))
+            _close(_edge(dx), xr.grad * (xe > 0), 5e-5, "bf16 dx (first/last 2 samples)")
+        return
     rq = _r16 if (conv_mode == "bf16" and Cin > 1 and Cout > 1) else (lambda t: t)     # (thin layers stay fp32 in every mode)
     y = ops.conv2d_fwd(x, w, b, relu_in=True)
     dx = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
@@ -163,6 +196,8 @@ def test_conv_wgrad_vs_oracle_at_launch_geometry(dev, conv_mode, B, H, W, Cin, C
     """Whole-tensor dW (and the fused bias gradient) of the full batch: pixel chunking, the per-sample factors of the
     shared backward sweep (`scaled`) and the float-atomic partial sums all take part."""
     from scrabble_gan_amd import ops
+    if conv_mode == "fp8":
+        pytest.skip("fp8 weight-grads: tests/test_fp8_gpu.py")
     g = torch.Generator(device=dev).manual_seed(B + H + Cin + k)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g)
     dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
@@ -188,6 +223,8 @@ def test_conv_transpose_vs_oracle_at_launch_geometry(dev, conv_mode, H, W, Cin, 
     """The generator's three Conv2DTranspose layers (+ a 1x1 stride-2 shortcut) at bs 128: y / dx on the first and
     last two samples; dW of the whole batch on the cheapest layer."""
     from scrabble_gan_amd import ops
+    if conv_mode == "fp8":
+        pytest.skip("transposed convs run the bf16 kernels in fp8 mode (covered by the bf16 mode)")
     B = 128
     g = torch.Generator(device=dev).manual_seed(H + Cin + k)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g)
@@ -217,3 +254,36 @@ def test_conv_transpose_vs_oracle_at_launch_geometry(dev, conv_mode, H, W, Cin, 
             O.conv2d_transpose(xc[lo:lo + 32], wz, None, stride).backward(dyc[lo:lo + 32])
             tot += wz.grad
         _close(dw, tot, 1e-4, "convT dW (whole batch)")
+
+
+@pytest.mark.parametrize("mode", ["f32-v2", "bf16", "fp8"])
+def test_deterministic_mode_covers_both_kernel_generations(dev, mode):
+    """configure(deterministic=True) -> sg_set_deterministic(1) must reach the second-generation (DMA-fed) kernels too (ADVICE
+    r2): with it, a sample's forward / data-grad result is BITWISE independent of the batch it is launched in, at shapes whose
+    tile count is not a multiple of the 256 CUs (the default launch would cut the tail tiles along the reduction and add
+    partial tiles with float atomics)."""
+    from scrabble_gan_amd import ops
+    from scrabble_gan_amd._lib import lib
+    g = torch.Generator(device=dev).manual_seed(3)
+    H, W, C = 8, 40, 512
+    x = torch.randn(13, H, W, C, device=dev, generator=g)
+    w = torch.randn(3, 3, C, C, device=dev, generator=g) / 64
+    dy = torch.randn(13, H, W, C, device=dev, generator=g)
+    old_min = ops.F32_V2_MIN_TILES
+    try:
+        if mode == "f32-v2":
+            ops.F32_V2_MIN_TILES = 0
+        else:
+            ops.set_conv_dtype(mode)
+        ops.set_deterministic(True)
+        assert lib().sg_set_deterministic(1) == 1                  # (returns the previous setting)
+        y5, y13 = ops.conv2d_fwd(x[:5].contiguous(), w), ops.conv2d_fwd(x, w)
+        d5, d13 = ops.conv2d_bwd_data(dy[:5].contiguous(), w, (H, W)), ops.conv2d_bwd_data(dy, w, (H, W))
+        if mode == "fp8":      # per-tensor amax depends on the batch: compare two launches of the same batch instead
+            assert torch.equal(ops.conv2d_fwd(x, w), y13) and torch.equal(ops.conv2d_bwd_data(dy, w, (H, W)), d13)
+        else:
+            assert torch.equal(y5, y13[:5]) and torch.equal(d5, d13[:5])
+    finally:
+        ops.set_deterministic(False)
+        ops.F32_V2_MIN_TILES = old_min
+        ops.set_conv_dtype("f32")

@@ -105,7 +105,7 @@ int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, in
 int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void* dy16, float* dw, int B, int H, int W, int Cin, int Cout,
                                           int kh, int kw, int sh, int sw, void* stream);
 
-/* ---- fp8 (OCP e4m3) operands for the forward / data-grad convolutions (BASELINE config c5, first slice): per-tensor
+/* ---- fp8 (OCP e4m3) operands for the forward / data-grad convolutions (BASELINE config c5): per-tensor
  *      scaling operand8 = e4m3(value * 448 / amax), amax = max|tensor| kept as a DEVICE scalar (no host sync), fp32
  *      accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, result = sums * amax_a * amax_w / 448^2.
  *      sg_amax_f32: amax[0] = max(amax[0], max|x|) (zero it first; n % 4 == 0).  sg_cvt_fp8: fp32 -> fp8 with that scale,
@@ -121,6 +121,20 @@ int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, cons
 int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, const void* wp8, const float* amax_w, const float* mask,
                            const void* mask16, float* dx, void* dx16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                            int pad_same, int flags, void* stream);
+/* fp8 weight gradient (config c5; resnet_ops.py:98,103,109 call sites of the D-shaped trunks, reverse pass of the tapes at
+ * data_utils.py:449-468): dw fp32 [kh,kw,Cin,Cout] += sum over pixels of x8 (e4m3, the forward launch's operand copy, ReLU
+ * folded in) x dy8 (OCP e5m2 = e5m2(clamp(rowscale * dy * 57344 / amax_dy)), per-sample factors folded in) times
+ * amax_x amax_dy / (448 * 57344), on v_mfma_scale_f32_32x32x64_f8f6f4 (A e4m3, B e5m2), fp32 accumulation.  SAME stride-1
+ * or 1x1 convolutions with Cin % 256 == 0 and Cout % 256 == 0, else SG_ERR_UNSUPPORTED (caller: the bf16 entry point).
+ * sg_amax2_f32: amax2[0] = max(amax2[0], max |x|), amax2[1] = max(amax2[1], max |rowscale[i / rowlen] x_i|) in ONE read
+ * sweep (zero amax2 first; n % 4 == 0).  sg_cvt_fp8_grad: one sweep over a gradient [M, C] -> the e5m2 weight-grad
+ * operand (scaled rows), the e4m3 data-grad operand (nullable; unscaled rows, scale 448 / amax2[0]) and dbias [C] +=
+ * fp32 column sums of the scaled values (nullable) -- the fp8 counterpart of sg_cvt_bf16_bias. */
+int sg_conv2d_bwd_weight_fp8(const void* x8, const float* amax_x, const void* dy8, const float* amax_dy, float* dw, int B, int H,
+                             int W, int Cin, int Cout, int kh, int kw, int pad_same, void* stream);
+int sg_amax2_f32(const float* x, long n, const float* rowscale, long rowlen, float* amax2, void* stream);
+int sg_cvt_fp8_grad(const float* x, void* out_e5m2, void* out_e4m3, long M, int C, const float* rowscale, long rows_per_sample,
+                    const float* amax2, float* dbias, void* stream);
 
 /* bf16 variants of the transposed convolution (w [kh,kw,Cout,Cin]): forward wp = pack(w, kh*kw, K = Cin, N = Cout,
  * transpose = 0); data-grad wp = pack(w, kh*kw, K = Cout, N = Cin, transpose = 1).  SG_ERR_UNSUPPORTED for a stride /

@@ -29,6 +29,14 @@ BN_MOMENTUM = 0.99     # Keras default momentum
 # --------------------------------------------------------------------------------------------
 # primitives (TF semantics)
 # --------------------------------------------------------------------------------------------
+RELU_HOOK = None       # tests only: callable(x) -> relu(x), sees every ReLU ACTIVATION site in call order (tests/step_fixture.py)
+
+
+def relu(x: Tensor) -> Tensor:
+    """tf.nn.relu / layers.ReLU at an activation site of the networks (resnet_ops.py:51,63,97,102; net_architecture.py:250,282)."""
+    return RELU_HOOK(x) if RELU_HOOK is not None else torch.relu(x)
+
+
 def _nchw(x: Tensor) -> Tensor:
     return x.permute(0, 3, 1, 2)
 
@@ -163,8 +171,8 @@ def ctc_batch_cost(y_true: Tensor, y_pred: Tensor, input_length: int, label_leng
 # --------------------------------------------------------------------------------------------
 def resnet_block_down(x: Tensor, p: Dict[str, Tensor], pre: str, is_last: bool) -> Tensor:
     """ResNetBlockDown.call (resnet_ops.py:93-115)."""
-    net = conv2d(torch.relu(x), p[pre + ".conv1.w"], p[pre + ".conv1.b"])      # :97-99
-    net = conv2d(torch.relu(net), p[pre + ".conv2.w"], p[pre + ".conv2.b"])    # :102-104
+    net = conv2d(relu(x), p[pre + ".conv1.w"], p[pre + ".conv1.b"])            # :97-99
+    net = conv2d(relu(net), p[pre + ".conv2.w"], p[pre + ".conv2.b"])          # :102-104
     if not is_last:
         net = avg_pool2(net)                                                   # :105-106
     sc = conv2d(x, p[pre + ".short.w"], p[pre + ".short.b"])                   # :109-111
@@ -181,9 +189,9 @@ def resnet_block_up(x: Tensor, z: Tensor, p: Dict[str, Tensor], pre: str, is_las
     s2 = {} if bn_stats is not None else None
     m1 = None if training else (p[pre + ".cbn1.mm"], p[pre + ".cbn1.mv"])
     m2 = None if training else (p[pre + ".cbn2.mm"], p[pre + ".cbn2.mv"])
-    net = torch.relu(conditional_batch_norm(x, z, p[pre + ".cbn1.gamma.w"], p[pre + ".cbn1.beta.w"], s1, m1))
+    net = relu(conditional_batch_norm(x, z, p[pre + ".cbn1.gamma.w"], p[pre + ".cbn1.beta.w"], s1, m1))
     net = conv2d_transpose(net, p[pre + ".convT.w"], p[pre + ".convT.b"], stride)
-    net = torch.relu(conditional_batch_norm(net, z, p[pre + ".cbn2.gamma.w"], p[pre + ".cbn2.beta.w"], s2, m2))
+    net = relu(conditional_batch_norm(net, z, p[pre + ".cbn2.gamma.w"], p[pre + ".cbn2.beta.w"], s2, m2))
     net = conv2d(net, p[pre + ".conv.w"], p[pre + ".conv.b"])
     sc = conv2d_transpose(x, p[pre + ".short.w"], p[pre + ".short.b"], stride)
     if bn_stats is not None and training:
@@ -206,7 +214,7 @@ def disc_trunk(x: Tensor, p: Dict[str, Tensor], nl: Optional[Dict[str, Tensor]],
         net = resnet_block_down(net, p, name, is_last=(i == 3))
         if name in attn_blocks:
             net = nonlocal_block(net, nl["theta"], nl["phi"], nl["g"], nl["o"], p["NL_" + name + ".sigma"])
-    return torch.relu(net).mean(dim=(1, 2))
+    return relu(net).mean(dim=(1, 2))
 
 
 def discriminator(x: Tensor, p: Dict[str, Tensor], nl: Optional[Dict[str, Tensor]] = None,
@@ -275,7 +283,7 @@ def generator(style: Tensor, y: Tensor, p: Dict[str, Tensor], nl_style: Dict[str
     x_hat, mean, var = batch_norm_train(net)                                   # :281
     if bn_stats is not None:
         bn_stats["bn"] = {"mean": mean.detach(), "var": var.detach(), "count": net.numel() // net.shape[-1]}
-    net = torch.relu(x_hat * p["bn.gamma"] + p["bn.beta"])                     # :282
+    net = relu(x_hat * p["bn.gamma"] + p["bn.beta"])                           # :282
     net = conv2d(net, p["final.w"], p["final.b"])                              # :283-287
     return torch.tanh(net)                                                     # :289
 

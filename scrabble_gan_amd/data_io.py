@@ -89,12 +89,16 @@ def load_style_input(input_dim, batch_size, bucket_size, style_dir="../../scrabb
 
 
 class DevicePrefetcher:
-    """Host pipeline of SURVEY 8(f)-3 around a raw (uint8) batch generator: a background thread pulls the next batches and
-    stages their pixels in PINNED host buffers (torch's caching host allocator); next() queues an asynchronous
-    host-to-device copy of the bytes (a quarter of the fp32 volume) and the GPU-side pixel normalisation
-    (sg_normalize_u8 = data_utils.py:82) on the current stream and returns (images fp32 on the device, labels int32 numpy):
-    train_step takes device tensors as they are.  The generator itself runs on ONE thread in its own order, so the
-    `random` / `np.random` draw sequence of the reference loader is unchanged.  depth = batches staged ahead."""
+    """Host pipeline of SURVEY 8(f)-3 around a raw (uint8) batch generator.  The GENERATOR is pulled on the consumer's thread
+    (at construction for the first `depth` batches, then one more per next()): it draws from the global `random` /
+    `np.random` streams that train_step's fake-label draw and main.py's style split use too, so pulling it from a background
+    thread would interleave the two consumers of those streams by timing -- a seeded run would not reproduce and
+    data-parallel ranks would not see the same global batch.  Here the interleaving is a fixed function of the
+    call sequence; the generator's own draw order is the reference loader's.  A background thread does the byte work only:
+    it stages the pixels in PINNED host buffers (torch's caching host allocator); next() queues an asynchronous
+    host-to-device copy of the bytes (a quarter of the fp32 volume) and the GPU-side pixel normalisation (sg_normalize_u8 =
+    data_utils.py:82) on the current stream and returns (images fp32 on the device, labels int32 numpy): train_step takes
+    device tensors as they are.  depth = batches staged ahead."""
 
     def __init__(self, raw_batches, device, depth: int = 2):
         import queue
@@ -102,14 +106,19 @@ class DevicePrefetcher:
         import torch
         self._torch = torch
         self._device = torch.device(device)
-        self._q = queue.Queue(maxsize=max(1, depth))
-        self._stop = False
+        self._it = iter(raw_batches)
+        self._in = queue.Queue()
+        self._q = queue.Queue()
+        self._exhausted = False
 
         def work():
-            try:
-                for u8, labels in raw_batches:
-                    if self._stop:
-                        return
+            while True:
+                item = self._in.get()
+                if item is None:
+                    self._q.put(None)
+                    return
+                try:
+                    u8, labels = item
                     u8 = np.ascontiguousarray(u8, dtype=np.uint8)
                     n = u8.size
                     pad = (-n) % 16                                   # the kernel converts 16 pixels per thread
@@ -118,12 +127,23 @@ class DevicePrefetcher:
                     if pad:
                         buf[n:].zero_()
                     self._q.put((buf, u8.shape, labels))
-                self._q.put(None)
-            except Exception as e:  # noqa: BLE001  (surface loader errors in the consumer)
-                self._q.put(e)
+                except Exception as e:  # noqa: BLE001  (surface staging errors in the consumer)
+                    self._q.put(e)
 
         self._thread = threading.Thread(target=work, daemon=True)
         self._thread.start()
+        for _ in range(max(1, depth)):
+            self._feed()
+
+    def _feed(self):
+        """Pull ONE batch from the generator on the calling thread and hand it to the staging thread."""
+        if self._exhausted:
+            return
+        try:
+            self._in.put(next(self._it))
+        except StopIteration:
+            self._exhausted = True
+            self._in.put(None)
 
     def __iter__(self):
         return self
@@ -132,13 +152,17 @@ class DevicePrefetcher:
         from . import ops
         item = self._q.get()
         if item is None:
+            self._q.put(None)
             raise StopIteration
         if isinstance(item, Exception):
             raise item
+        self._feed()
         buf, shape, labels = item
         n = int(np.prod(shape))
         dev8 = buf.to(self._device, non_blocking=True)
         return ops.normalize_u8(dev8)[:n].view(*shape), labels
 
     def close(self):
-        self._stop = True
+        if not self._exhausted:
+            self._exhausted = True
+            self._in.put(None)

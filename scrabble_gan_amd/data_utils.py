@@ -101,6 +101,9 @@ def _pad4(t):
     return out
 
 
+DEBUG_KEEP = None      # tests set a dict here to receive the generator's saved context of the next train_step
+
+
 # ------------------------------------------------------------------------------------------------
 def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discriminator, recognizer, style_promoter, composite_gan,
                generator_optimizer, discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer, my_imgs,
@@ -164,6 +167,8 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     # no BatchNorm and the frozen R normalises with moving statistics, so samples are independent and the result is
     # the same; each call keeps its own NonLocalBlock kernels (passes may be re-ordered).
     x_f, ctx_g = G.forward(style, fake_t, nl.get("G.style"), nl.get("G.up"), training=True)
+    if DEBUG_KEEP is not None:
+        DEBUG_KEEP["ctx_g"] = ctx_g                                 # (tests: the ReLU decisions the forward pass took)
     B = x_f.shape[0]
     il_f, il_r = ctc_input_length(L_f), ctc_input_length(L_r)
     plain = all(getattr(m, "supports_fused_passes", True) for m in (D, S))     # (make_my_discriminator: separate passes and sweeps)
@@ -262,21 +267,32 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         dx = ops.add(dx_d, dx_s, out=dx_d)
         ctx_rf_ = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
         ops.add(dx, R.backward(ctx_rf_, gG_r, want_dx=True, want_dw=False), out=dx)
-        # G's buffer is reduced in two slices: [zdense.w .. end] (filter bank, up blocks, head) as soon as it is final,
-        # under the style encoder's backward; [0 .. zdense.w) after it
-        g_tail = []
-        G.backward(ctx_g, dx, on_tail_ready=(lambda off: g_tail.append((off, red.all_reduce_sum_async(G.store.grad[off:]))))
-                   if red.world_size > 1 else None)
+        # G's buffer is reduced in slices as its backward finalises them: [zdense.w .. end] (filter bank, up blocks, head)
+        # first, under the style encoder's backward; then each style-encoder block's range right after that block's
+        # backward (B_style4: 80 MB, B_style3: 59 MB, B_style2: 11 MB, B_style1: 0.2 MB) -- only the last, smallest slices
+        # are not hidden behind compute.  Whatever the callbacks did not cover is reduced at the end.
+        g_parts = []          # (lo, hi, handle)
+        applied = getattr(G, "kernel_reg_mode", "reference") == "applied" and getattr(G, "kernel_reg", None) is not None
+        if red.world_size > 1 and not applied:
+            n_flat = G.store.grad.numel()
+            G.backward(ctx_g, dx,
+                       on_tail_ready=lambda off: g_parts.append((off, n_flat, red.all_reduce_sum_async(G.store.grad[off:]))),
+                       on_slice_ready=lambda lo, hi: g_parts.append((lo, hi, red.all_reduce_sum_async(G.store.grad[lo:hi]))))
+        else:
+            G.backward(ctx_g, dx)
 
     # ---- finish the gradient exchange and update: each network as soon as ITS exchange is done, so the updates of
     #      D / R / S run under G's all-reduce ----
     g_handles = []
     if g_step:
-        if g_tail:
-            off, h_tail = g_tail[0]
-            g_handles = [red.all_reduce_sum_async(G.store.grad[:off]), h_tail]
-        else:
-            g_handles = [red.all_reduce_sum_async(G.store.grad)]
+        n_flat = G.store.grad.numel()
+        covered = sorted((lo, hi) for lo, hi, _ in g_parts)
+        g_handles = [h for _, _, h in g_parts]
+        pos = 0
+        for lo, hi in covered + [(n_flat, n_flat)]:          # the gaps the callbacks left (everything, on one rank / applied mode)
+            if lo > pos:
+                g_handles.append(red.all_reduce_sum_async(G.store.grad[pos:lo]))
+            pos = max(pos, hi)
     for h, opt, m in zip(pending, (discriminator_optimizer, recognizer_optimizer, stylepromoter_optimizer), (D, R, S)):
         red.wait(h)
         opt.apply_flat(m.store)

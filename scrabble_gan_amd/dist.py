@@ -77,6 +77,8 @@ class AbiReducer(DistReducer):
         call("sg_rccl_comm_init_rank", ctypes.addressof(comm), self.world_size, raw, self.rank)
         self._comm = comm.value
         self._side = torch.cuda.Stream()
+        import atexit
+        atexit.register(self.close)             # the communicator is destroyed at interpreter shutdown at the latest
 
     _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 3}
 
@@ -87,6 +89,9 @@ class AbiReducer(DistReducer):
         ready = torch.cuda.Event()
         ready.record(cur)
         self._side.wait_event(ready)
+        # the collective reads and writes `t` on the side stream: tell the caching allocator, so that a temporary freed
+        # before wait() is not handed out again while RCCL still works on it
+        t.record_stream(self._side)
         self._call("sg_allreduce_sum", t.data_ptr(), t.numel(), self._DT[t.dtype], self._comm, self._side.cuda_stream)
         done = torch.cuda.Event()
         done.record(self._side)
@@ -104,9 +109,12 @@ class AbiReducer(DistReducer):
             torch.cuda.current_stream().wait_event(handle)
 
     def close(self):
-        if self._comm:
-            self._call("sg_rccl_comm_destroy", self._comm)
-            self._comm = None
+        if getattr(self, "_comm", None):
+            try:
+                self._side.synchronize()
+                self._call("sg_rccl_comm_destroy", self._comm)
+            finally:
+                self._comm = None
 
 
 def init_from_env(backend: str = "nccl") -> "Reducer":

@@ -210,14 +210,16 @@ class _DownTrunk:
         """The saved context of batch rows [lo, hi) of a multi-segment pass (segment-aligned)."""
         ctxs, net = ctx
         out = []
-        for (x, c1), nlc in ctxs:
+        for (x, c1, xp), nlc in ctxs:
             if nlc is not None:
                 assert nlc[0] == "seg"
                 nlc = ("seg", [(a - lo, b - lo, c) for a, b, c in nlc[1] if a >= lo and b <= hi])
-            out.append(((x[lo:hi], c1[lo:hi]), nlc))
+            out.append(((x[lo:hi], c1[lo:hi], None if xp is None else xp[lo:hi]), nlc))
         return out, net[lo:hi]
 
-    def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool, wscale=None):
+    def bwd(self, ctx, dh, S: ParamStore, want_dx: bool, want_dw: bool, wscale=None, on_block_done=None):
+        """`on_block_done(lo, hi)` (optional) is called after each block's backward with the range of the flat gradient buffer
+        that is final from then on (that block's kernels and biases and its NonLocalBlock's parameters)."""
         ctxs, net = ctx
         d = ops.gap_bwd(dh, net, relu=True)
         for i in reversed(range(len(self.names))):
@@ -238,7 +240,18 @@ class _DownTrunk:
                 else:
                     d = nn.nonlocal_bwd(nlc, d, sigma, dsig, dnlw, wscale=wscale)
             d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw, wscale=wscale)
+            if on_block_done is not None:
+                lo = S._off[n + ".conv1.w"]
+                hi = S._off[self.names[i + 1] + ".conv1.w"] if i + 1 < len(self.names) else self.end_offset(S)
+                on_block_done(lo, hi)
         return d
+
+    def end_offset(self, S: ParamStore) -> int:
+        """Offset in the flat trainable buffer right behind this trunk's last parameter (trunk specs come first in every model)."""
+        last = self.specs()[-1]
+        import math as _m
+        n = int(_m.prod(last[1])) if len(last[1]) else 1
+        return S._off[last[0]] + (n + 3) // 4 * 4
 
 
 class DiscriminatorModel(_Model):
@@ -386,13 +399,16 @@ class GeneratorModel(_Model):
         img = ops.conv2d_fwd(yb, p["final.w"], p["final.b"], tanh_out=True)        # :283-289
         return img, (tctx, h, z, y, up_ctx, bctx, yb, img, S)
 
-    def backward(self, ctx, dimg, on_tail_ready=None):
-        """`on_tail_ready(offset)` (optional) is called once every gradient in `store.grad[offset:]` is final."""
+    def backward(self, ctx, dimg, on_tail_ready=None, on_slice_ready=None):
+        """`on_tail_ready(offset)` (optional) is called once every gradient in `store.grad[offset:]` is final;
+        `on_slice_ready(lo, hi)` (optional) after each style-encoder block's backward with the range of the flat gradient
+        buffer that is final from then on -- data parallelism reduces G's 214 MB in slices while the rest of its backward
+        still runs, so only the last (smallest) block's bytes are exposed."""
         tctx, h, z, y, up_ctx, bctx, yb, img, S = ctx
         p, g = S.p, S.g
         applied = isinstance(S, nn.AppliedSNStore)
         if applied:
-            on_tail_ready = None        # the shadow gradients are folded at the end: no early slice of the flat buffer is final
+            on_tail_ready = on_slice_ready = None        # the shadow gradients are folded at the end: no early slice of the flat buffer is final
         d_pre = ops.tanh_bwd(img, dimg)
         ops.conv2d_bwd_weight(yb, d_pre, g["final.w"])
         ops.bias_grad(d_pre, g["final.b"])
@@ -413,7 +429,7 @@ class GeneratorModel(_Model):
             # complete: data parallelism starts reducing that slice while the style encoder's backward still runs
             on_tail_ready(S._off["zdense.w"])
         dh = ops.dense_bwd_input(dz, p["zdense.w"])
-        self.trunk.bwd(tctx, dh, S, want_dx=False, want_dw=True)
+        self.trunk.bwd(tctx, dh, S, want_dx=False, want_dw=True, on_block_done=on_slice_ready)
         self._fold(S)
 
     def __call__(self, inputs, training=False):

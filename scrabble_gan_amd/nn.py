@@ -198,34 +198,55 @@ def block_down_specs(pre: str, cin: int, cout: int):
             (pre + ".short.w", (1, 1, cin, cout), orthogonal, True), (pre + ".short.b", (cout,), zeros, True)]
 
 
+POOL_FIRST_SHORTCUT = True
+
+
 def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
+    """The shortcut branch of a pooling block is avg_pool(conv1x1(x) + b) (resnet_ops.py:109-113).  A 1x1 convolution and a
+    2x2 mean are both linear and act on different axes, so it equals conv1x1(avg_pool(x)) + b: the SAME sums in another
+    order, on a quarter of the pixels (4x fewer FLOPs for the forward, data-grad and weight-grad launches of every pooled
+    shortcut; they are the least efficient MFMA launches of the step: 64 / 512 reduction terms).  POOL_FIRST_SHORTCUT = False
+    keeps the reference's order; both are parity-tested against the oracle (which pools last)."""
     p = S.p
     c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True, want16=True)          # :97-99
+    xp = None
     if is_last:
         out = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])                     # :109-111
         ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True, out=out, accum=True)   # :102-104,114
+    elif POOL_FIRST_SHORTCUT and x.shape[-1] % 4 == 0:
+        c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
+        xp = ops.avgpool2_add_fwd(x)                                                          # pooled block input
+        out = ops.avgpool2_add_fwd(c2)                                                        # :105-106
+        ops.conv2d_fwd(xp, p[pre + ".short.w"], p[pre + ".short.b"], out=out, accum=True)     # :109-114, pooled first
     else:
         c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
         s = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])
         out = ops.avgpool2_add_fwd(c2, s)                                                     # :105-106,112-114
-    return out, (x, c1)
+    return out, (x, c1, xp)
 
 
 def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: bool, want_dw: bool, wscale=None):
     """`wscale` [B] (optional) weights each sample's contribution to the WEIGHT gradients only (shared backward sweep)."""
-    x, c1 = ctx
+    x, c1, xp = ctx
     p, g = S.p, S.g
     H, W = x.shape[1], x.shape[2]
-    d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of both conv2's output and the 1x1 output
+    d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of conv2's output (and of the 1x1 output when it pools last)
+    pooled_short = xp is not None
     if want_dw:
         ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
-        ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
+        if pooled_short:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
+            ops.conv2d_bwd_weight(xp, dout, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
+        else:
+            ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=True)
     if want_dw:
         ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
     if not want_dx:
         return None
-    dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
+    if pooled_short:
+        dx = ops.avgpool2_bwd(ops.conv2d_bwd_data(dout, p[pre + ".short.w"], (H // 2, W // 2)))
+    else:
+        dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
     ops.conv2d_bwd_data(d_c1, p[pre + ".conv1.w"], (H, W), mask=x, out=dx, accum=True)
     return dx
 

@@ -195,6 +195,41 @@ def fp8_of(t: torch.Tensor, relu: bool = False):
     return e[1], e[2]
 
 
+def _fp8_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool) -> bool:
+    """config c5: the weight-grad launches that run on fp8 operands (e4m3 activations x e5m2 gradients): the layers whose
+    forward / data-grad launches are fp8 and whose channel counts fill the kernel's 256 x 256 tile."""
+    return USE_V2 and CONV_DTYPE == "fp8" and not _FP8_BLOCK[0] and Cin % 256 == 0 and Cout % 256 == 0 and (same or (kh == 1 and kw == 1))
+
+
+def grad_operand_fp8(dy: torch.Tensor, sample_scale, want_colsum: bool):
+    """The fp8 weight-grad operand of a gradient tensor: (e5m2 copy of sample_scale[b] * dy[b] as uint8, its amax device scalar,
+    fp32 column sums or None).  ONE amax sweep (max |dy| and max |scale dy| together) and ONE convert sweep yield that copy, the
+    column sums (= the bias gradient) and -- when the gradient has none yet -- the e4m3 copy the data-grad launch of the same
+    gradient reads (registered under fp8_of's key); kept for the step."""
+    key = (dy.untyped_storage().data_ptr(), "g8", 0 if sample_scale is None else sample_scale.data_ptr(), dy.storage_offset(), dy.numel())
+    e = _TWINS.get(key)
+    if e is None or (want_colsum and e[4] is None):
+        _chk(dy, sample_scale)
+        C = dy.shape[-1]
+        M = dy.numel() // C
+        k4 = (dy.untyped_storage().data_ptr(), "fp8", False, dy.storage_offset(), dy.numel())
+        have4 = k4 in _TWINS
+        amax2 = torch.zeros(2, device=dy.device)
+        out5 = torch.empty(dy.shape, device=dy.device, dtype=torch.uint8)
+        out4 = None if have4 else torch.empty(dy.shape, device=dy.device, dtype=torch.uint8)
+        colsum = torch.zeros(C, device=dy.device, dtype=torch.float32)
+        rows = (M // sample_scale.numel()) if sample_scale is not None else 1
+        with _hbm("cvt_fp8", dy, dy, out5, out4):
+            call("sg_amax2_f32", _p(dy), dy.numel(), _p(sample_scale), rows * C, _p(amax2), _stream())
+            call("sg_cvt_fp8_grad", _p(dy), out5.data_ptr(), None if out4 is None else out4.data_ptr(), M, C, _p(sample_scale), rows,
+                 _p(amax2), _p(colsum), _stream())
+        if out4 is not None:
+            _TWINS[k4] = (dy, out4, amax2[0:1])
+        e = (dy, sample_scale, out5, amax2[1:2], colsum)
+        _TWINS[key] = e
+    return e[2], e[3], e[4]
+
+
 def packed_filter_fp8(w: torch.Tensor, kind: str):
     """-> (fp8 copy [tap][N][K] of a Conv2D filter scaled by 448 / amax, amax device scalar); made once per optimizer step."""
     key = (w.data_ptr(), tuple(w.shape), kind + "8", w._version)
@@ -480,6 +515,15 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
+    if _fp8_wgrad_ok(Cin, Cout, kh, kw, same):
+        # config c5: e4m3 activations (the copy the forward launch read: ReLU folded into the conversion) x e5m2 gradients
+        x8, ax = fp8_of(x, relu_in)
+        dy8, ady, colsum = grad_operand_fp8(dy, sample_scale, db is not None)
+        if db is not None:
+            add(db, colsum, out=db)
+        with _timed("wgrad_fp8", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
+            call("sg_conv2d_bwd_weight_fp8", x8.data_ptr(), _p(ax), dy8.data_ptr(), _p(ady), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _stream())
+        return
     if USE_V2 and _low() and (same or kh * kw == 1) and ((Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)):
         # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy, whose
         # conversion sweep also yields the bias gradient (fp32 column sums) and, if missing, the plain twin for the data-grad

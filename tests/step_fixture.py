@@ -46,8 +46,35 @@ def make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=300.0, z_sca
     return dict(P=P, images=images, style=style, labels=labels, fake=fake, nl=nl, B=B, L_r=L_r, L_f=L_f)
 
 
-def run_oracle(pb, dtype, loss_name="hinge", balance=False):
-    """-> (16 scalars, {net: {name: grad}}, {net: {name: post-update weight}}, fake images); pb is not modified."""
+G_RELU_SITES = 16      # ReLU activation sites of one generator forward, in the oracle's call order: style encoder
+                       # B_style1..4 x (relu(x), relu(conv1)), relu before GAP, B1..B3 x (cbn1, cbn2), the final BN
+
+
+def run_oracle(pb, dtype, loss_name="hinge", balance=False, relu_sites=None, forced=None):
+    """-> (16 scalars, {net: {name: grad}}, {net: {name: post-update weight}}, fake images); pb is not modified.
+    relu_sites (list, optional): receives the PRE-activation tensor of each of the generator's G_RELU_SITES ReLU sites.
+    forced (list of bool tensors or None per site, optional): the counterfactual oracle -- at those sites the ReLU DECISION is
+    imposed (y = x * mask, so the backward mask follows) instead of taken from the sign of the fp64 pre-activation."""
+    calls = [0]
+
+    def hook(x):
+        i = calls[0]
+        calls[0] += 1
+        if i < G_RELU_SITES:
+            if relu_sites is not None:
+                relu_sites.append(x.detach().clone())
+            if forced is not None and forced[i] is not None:
+                return x * forced[i].to(x.dtype)
+        return torch.relu(x)
+
+    O.RELU_HOOK = hook if (relu_sites is not None or forced is not None) else None
+    try:
+        return _run_oracle(pb, dtype, loss_name, balance)
+    finally:
+        O.RELU_HOOK = None
+
+
+def _run_oracle(pb, dtype, loss_name, balance):
     cast = lambda t: t.to(dtype) if t.is_floating_point() else t
     P = {n: {k: cast(v.clone()) for k, v in W.items()} for n, W in pb["P"].items()}
     nl = {n: {k: cast(v) for k, v in d.items()} for n, d in pb["nl"].items()}
@@ -60,9 +87,49 @@ def run_oracle(pb, dtype, loss_name="hinge", balance=False):
 
 def calibrate(pb, loss_name="hinge", balance=False):
     """fp64 reference + the per-tensor deviation of the oracle's own fp32 evaluation from it."""
-    s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance)
+    sites64 = []
+    s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance, relu_sites=sites64)
     s32, g32, w32, x32 = run_oracle(pb, torch.float32, loss_name, balance)
     err32 = {n: {k: (g32[n][k].double() - v).abs().max().item() for k, v in g64[n].items()} for n in g64}
     l2err32 = {n: {k: (g32[n][k].double() - v).norm().item() for k, v in g64[n].items()} for n in g64}
     serr32 = [abs(a - b) for a, b in zip(s32, s64)]
-    return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, l2err32=l2err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item())
+    return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, l2err32=l2err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item(),
+                relu_sites64=sites64)
+
+
+def load_models(NA, pb, dev):
+    """The four networks of the HIP path carrying problem `pb`'s weights, + their NonLocalBlock kernels on the device."""
+    from scrabble_gan_amd import nn as _nn
+    _nn.FAST_INIT = True                # every weight is loaded from the fixture below: skip the QR initialisers
+    try:
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+    finally:
+        _nn.FAST_INIT = False
+    gan = NA.make_gan(G, D, R, S, vis_model=False)
+    models = {"G": G, "D": D, "R": R, "S": S}
+    for n, m in models.items():
+        assert set(m.store.names) == set(pb["P"][n]), (n, set(m.store.names) ^ set(pb["P"][n]))
+        m.store.load({k: v.float() for k, v in pb["P"][n].items()})
+    nlg = {n: {k: v.float().to(dev).contiguous() for k, v in d.items()} for n, d in pb["nl"].items()}
+    return models, gan, nlg
+
+
+def hip_relu_decisions(ctx_g):
+    """The ReLU decisions the HIP generator forward took, one bool tensor per site in the oracle's call order (G_RELU_SITES),
+    from the context train_step saved: the style encoder applies its ReLUs in the consumers' operand loaders (decision = sign
+    of the saved fp32 pre-activation), the up blocks and the final BatchNorm materialise relu(.) (decision = output > 0)."""
+    tctx, h, z, y, up_ctx, bctx, yb, img, S = ctx_g
+    ctxs, net = tctx
+    dec = []
+    for (x, c1, _xp), _nl in ctxs:
+        dec += [x > 0, c1 > 0]
+    dec.append(net > 0)
+    for (c, _nl) in up_ctx:
+        x_in, c1, c2, stride = c
+        dec += [c1[1] > 0, c2[1] > 0]
+    dec.append(yb > 0)
+    assert len(dec) == G_RELU_SITES
+    return [d.cpu() for d in dec]

@@ -82,6 +82,73 @@ def test_conv2d_fp8_fwd_dgrad(dev, gen, fp8_mode, B, H, W, Cin, Cout, k):
         close(ops.conv2d_bwd_data(dyg, wg, (H, W)), xe.grad, 6e-2, "dgrad vs exact oracle")
 
 
+def q5(t32, amax):
+    """sg_cvt_fp8_grad's e5m2 operand on the host: e5m2(clamp(v * 57344 / amax)) as fp64 (v already carries its row factor)."""
+    s = (torch.tensor(57344.0) / amax.float()).float() if amax > 0 else torch.tensor(1.0)
+    return (t32.float() * s).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(torch.float64)
+
+
+WGRAD_CASES = [
+    # B, H, W, Cin, Cout, k, scaled
+    (2, 8, 12, 256, 256, 3, False),
+    (3, 8, 40, 512, 256, 1, True),      # 1x1 shortcut shape, two c-tiles, per-sample factors
+    (5, 7, 5, 256, 512, 3, True),       # odd spatial dims: M = 175 pixels, ragged last 128-pixel tile, two n-tiles
+    (40, 4, 20, 256, 256, 3, False),    # 3200 pixels: several pixel chunks per (tap, tile) -> atomically summed partial dW
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,scaled", WGRAD_CASES)
+def test_conv2d_fp8_wgrad(dev, gen, fp8_mode, B, H, W, Cin, Cout, k, scaled):
+    """fp8 weight gradient (e4m3 activations x e5m2 gradients, v_mfma_scale_f32_32x32x64_f8f6f4, transposing LDS reads) with the
+    fused bias gradient and the per-sample factors of the shared sweep: 5e-5 of max|ref| against the oracle on operands
+    quantised the same way (torch.float8_e4m3fn / float8_e5m2, same fp32 scale arithmetic), 8e-2 against the exact oracle
+    (e5m2 keeps 2 mantissa bits: 2^-3 relative per gradient element, random signs over >= 175 pixels)."""
+    ops = fp8_mode
+    x = rnd(gen, B, H, W, Cin)
+    dy = rnd(gen, B, H, W, Cout)
+    sc = (torch.rand(B, generator=gen, dtype=torch.float64) * 2 - 0.5) if scaled else None
+    xg, dyg = g32(x, dev), g32(dy, dev)
+    scg = None if sc is None else g32(sc, dev)
+    dw0 = rnd(gen, k, k, Cin, Cout)
+    dw, db = g32(dw0, dev), torch.zeros(Cout, device=dev)
+    ops.conv2d_bwd_weight(xg, dyg, dw, relu_in=True, db=db, sample_scale=scg)
+    x32 = x.float()
+    ax = x32.abs().max()
+    qx = (torch.relu(x32) * (torch.tensor(448.0) / ax).float()).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float64)
+    dys32 = dy.float() if sc is None else dy.float() * sc.float().view(B, 1, 1, 1)
+    aq = dys32.abs().max()
+    qd = q5(dys32, aq)
+    w = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d(qx, w, None).backward(qd)
+    scale = (ax.double() / 448.0) * (aq.double() / 57344.0)
+    close(dw, w.grad * scale + dw0, 5e-5, "fp8 dW (+=) vs oracle on the same quantised operands")
+    close(db, dys32.double().sum(dim=(0, 1, 2)), 5e-5, "fused bias gradient (fp32 sums of the scaled fp32 values)")
+    we = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d(torch.relu(x), we, None).backward(dys32.double())
+    close(dw - g32(dw0, dev), we.grad, 8e-2, "fp8 dW vs exact oracle")
+    # the data-grad launch of the same gradient reads the e4m3 copy that sweep wrote beside the e5m2 one
+    got4, a4 = ops.fp8_of(dyg)
+    want4 = (dy.float() * (torch.tensor(448.0) / dy.float().abs().max()).float()).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(got4.cpu(), want4) and a4.item() == dy.float().abs().max().item()
+
+
+def test_fp8_gradient_operand_matches_torch_e5m2(dev, gen, fp8_mode):
+    """sg_amax2_f32 + sg_cvt_fp8_grad bit for bit against torch.float8_e5m2 / float8_e4m3fn: scaled rows, values down in
+    e5m2's subnormal range and at the saturating end."""
+    ops = fp8_mode
+    B, C = 6, 64
+    dy = torch.cat([rnd(gen, B, 4, 5, C) * 3, rnd(gen, B, 4, 5, C) * 1e-4], 1).float().contiguous()      # [B, 8, 5, C]
+    sc = torch.tensor([1.0, -0.5, 2.0, 0.25, 1e-3, 0.0])
+    dyg, scg = dy.to(dev), sc.to(dev)
+    out5, a5, colsum = ops.grad_operand_fp8(dyg, scg, True)
+    dys = dy * sc.view(B, 1, 1, 1)
+    assert a5.item() == dys.abs().max().item()
+    want5 = (dys * (torch.tensor(57344.0) / dys.abs().max()).float()).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
+    g5, w5 = out5.cpu(), want5
+    assert torch.equal(g5 & 0x7f, w5 & 0x7f) and torch.equal((g5 ^ w5)[(w5 & 0x7f) != 0], torch.zeros_like(g5)[(w5 & 0x7f) != 0])   # (sign of a zero may differ)
+    close(colsum, dys.double().sum(dim=(0, 1, 2)), 2e-5, "column sums")
+
+
 def test_fp8_conversion_matches_torch_e4m3(dev, gen, fp8_mode):
     """sg_amax_f32 + sg_cvt_fp8 bit for bit against torch.float8_e4m3fn (same fp32 scale arithmetic), including values that
     land in e4m3's subnormal range and the saturating end."""

@@ -392,30 +392,23 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
     ref_scalars, ref_grads, ref_w = cal["scalars"], cal["grads"], cal["weights"]
     assert ref_scalars[12] > 0.05 and ref_scalars[11] > 0.05, "fixture lost its conditioning: std(g_loss), std(r_fake) = %r" % (ref_scalars[11:13],)
 
-    from scrabble_gan_amd import nn as _nn
-    _nn.FAST_INIT = True                # every weight is loaded from the fixture below: skip the QR initialisers
-    try:
-        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
-        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
-        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
-        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
-    finally:
-        _nn.FAST_INIT = False
-    gan = NA.make_gan(G, D, R, S, vis_model=False)
-    models = {"G": G, "D": D, "R": R, "S": S}
-    for n, m in models.items():
-        assert set(m.store.names) == set(pb["P"][n]), (n, set(m.store.names) ^ set(pb["P"][n]))
-        m.store.load({k: v.float() for k, v in pb["P"][n].items()})
-    nlg = {n: {k: v.float().to(dev).contiguous() for k, v in d.items()} for n, d in pb["nl"].items()}
+    models, gan, nlg = F.load_models(NA, pb, dev)
+    G, D, R, S = (models[n] for n in ("G", "D", "R", "S"))
     B = pb["B"]
     opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
-    out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0], opts[1],
-                        opts[2], opts[3], pb["style"].float().numpy(), B, 128, getattr(net_loss, loss_name), 1, int(balance), None, bucket_size, "",
-                        fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
+    DU.DEBUG_KEEP = keep = {}
+    try:
+        out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0], opts[1],
+                            opts[2], opts[3], pb["style"].float().numpy(), B, 128, getattr(net_loss, loss_name), 1, int(balance), None, bucket_size, "",
+                            fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
+    finally:
+        DU.DEBUG_KEEP = None
+    hip_decisions = F.hip_relu_decisions(keep["ctx_g"])
+    del keep
     assert len(out) == 16 and out[10] == 1
     for i, (a, b) in enumerate(zip(out, ref_scalars)):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), "scalar %d: %r vs %r (oracle fp32 deviates by %.1e)" % (i, a, b, cal["scalar_err32"][i])
-    report, bad, bounds, flips = [], [], {}, []
+    report, bad, bounds, flips, exempted = [], [], {}, [], []
     for net in ("D", "R", "S", "G"):
         model = models[net]
         at = net_atol(list(ref_grads[net].values()))
@@ -443,10 +436,44 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
                 # ConditionalBatchNorm over 32 pixels per sample moves one column of dgamma / dbeta and one 32-entry row of
                 # the filter-bank gradient by a few percent and nothing else.  Such isolated outliers (at most 64 elements
                 # of a tensor, the whole-tensor L2 criterion above still holding) are tolerated; anything wider is not.
+                # The exemption has to PROVE that claim: see the counterfactual oracle below.
                 n_out = int((diff > bound).sum().item())
                 flips.append("%s.%s: %d element(s) above the bound, max %.3e (bound %.3e)" % (net, k, n_out, err, bound))
-                if n_out > 64:
+                if n_out > 64 or net != "G":
                     bad.append("%s grad %s: |HIP-fp64| %.3e > bound %.3e at %d elements (oracle fp32 err %.3e, scale %.3e)" % (net, k, err, bound, n_out, e32, scale))
+                else:
+                    exempted.append((k, bound, at))
+    # ---- proof of the outlier exemption.  (1) Every ReLU decision of the HIP generator forward that differs from the fp64
+    # oracle's must sit within fp32 rounding of the boundary: |fp64 pre-activation| <= 2e-5 x the site's largest
+    # pre-activation (checked whether or not a tensor needed the exemption -- a decision that differs AWAY from zero is a
+    # wrong activation, not rounding).  (2) The fp64 oracle is re-evaluated with exactly those decisions imposed (the
+    # counterfactual: y = x * HIP's mask at the generator's 16 ReLU sites, backward mask included); against IT every exempted
+    # tensor must meet its calibrated bound at ALL elements.  An indexing error that touches <= 64 elements survives neither.
+    sites64 = cal["relu_sites64"]          # fp64 pre-activations of the generator's ReLU sites (recorded by the calibration run)
+    forced, n_flip = [], 0
+    for i, (pre, dec) in enumerate(zip(sites64, hip_decisions)):
+        assert pre.shape == dec.shape, (i, pre.shape, dec.shape)
+        flip = dec != (pre > 0)
+        nf = int(flip.sum().item())
+        if nf:
+            far = (pre.abs() * flip).max().item()
+            lim = 2e-5 * pre.abs().max().item()
+            flips.append("ReLU site %d: %d decision(s) differ from fp64, farthest pre-activation %.3e (limit %.3e)" % (i, nf, far, lim))
+            if far > lim:
+                bad.append("ReLU site %d: a decision differs from the fp64 oracle at |pre-activation| %.3e > %.3e (not a rounding flip)" % (i, far, lim))
+        n_flip += nf
+        forced.append(dec if nf else None)
+    if exempted:
+        if n_flip == 0:
+            bad.append("outliers in %s but NO ReLU decision of the generator differs from fp64: not a decision flip" % [k for k, _, _ in exempted])
+        else:
+            _, g_cf, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced)
+            for k, bound, at in exempted:
+                d_cf = (models["G"].store.g[k].detach().double().cpu() - g_cf["G"][k]).abs()
+                n_cf = int((d_cf > bound).sum().item())
+                flips.append("G.%s vs the counterfactual oracle (HIP's decisions imposed): max %.3e, %d element(s) above the bound %.3e" % (k, d_cf.max().item(), n_cf, bound))
+                if n_cf:
+                    bad.append("G grad %s: %d outlier(s) remain against the counterfactual oracle (max %.3e > bound %.3e): not explained by the ReLU flips" % (k, n_cf, d_cf.max().item(), bound))
     # what the calibration looked like (kept by gpurun under gpurun_out/ for DESIGN.md)
     try:
         import os

@@ -70,51 +70,42 @@ def test_widest_bucket_and_bilstm_recognizer_step(dev):
 def test_shared_sweeps_and_fused_passes_equal_the_reference_schedule(dev):
     """train_step's default schedule (fused passes over concatenated batches, ONE backward sweep through D(x_f) / S(x_f)
     serving both the weight and the image gradient) against the reference's own schedule (every call its own pass, every
-    tape its own sweep: fuse_passes=False, share_backward=False) on identical weights and inputs: same 16 scalars, same
-    gradients of all four networks, same post-Adam weights."""
+    tape its own sweep: fuse_passes=False, share_backward=False) on identical weights and inputs, WITH gradient balancing:
+    same 16 scalars (1e-5), same gradients of all four networks -- G included -- within 1e-3 of the network's largest
+    gradient, same post-Adam weights.  The problem is the well-conditioned B = 8 fixture of tests/step_fixture.py
+    (std(g_loss), std(r_fake) = O(1); all widths equal, so every pass fuses) -- VERDICT r2 weak #4(b): the former B = 4
+    random-weight problem divided by a near-zero std and needed 5e-2 for G."""
     import numpy as np
     import torch
-    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, nn, optimizers
-    from scrabble_gan_amd._lib import lib
-    gen = torch.Generator().manual_seed(21)
-    B, L = 4, 2
-    images = (torch.rand(B, 32, 16 * L, 1, generator=gen) * 2 - 1).numpy()
-    style = (torch.rand(B, 32, 32, 1, generator=gen) * 2 - 1).numpy()        # 32 wide like the words: all passes fuse
-    labels = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
-    fake = torch.randint(0, 52, (B, L), generator=gen).numpy().astype(np.int32)
+    from tests import step_fixture as F
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, optimizers
+    from scrabble_gan_amd import ops
+    pb = F.make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=70.0)
+    B = pb["B"]
     res = {}
-    lib().sg_debug_set_splitk(1)        # batch-size dependent reduction splits would move forward bits (see test_dp_gpu.py)
+    ops.set_deterministic(True)        # batch-size dependent reduction splits would move forward bits (see test_dp_gpu.py)
     try:
         for mode, kw in (("default", {}), ("reference", {"fuse_passes": False, "share_backward": False})):
             NA._model_counter[0] = 0
             NA.configure(device=dev, seed=9)
-            G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
-            D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
-            R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
-            S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
-            gan = NA.make_gan(G, D, R, S, vis_model=False)
-            for m in (G, D, S):
-                for k in m.store.names:
-                    if k.endswith(".sigma"):
-                        m.store.p[k].fill_(0.25)
-            g2 = torch.Generator().manual_seed(5)
-            nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
-                  for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
+            models, gan, nlg = F.load_models(NA, pb, dev)
+            G, D, R, S = (models[n] for n in ("G", "D", "R", "S"))
             opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
-            out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], style, B, 128,
-                                net_loss.hinge, 1, 1, None, 10, "", fake_labels=fake, nl=nl, verbose=False, **kw)
-            res[mode] = (np.array(out, np.float64), {n: (m.store.grad.clone(), m.store.flat.clone()) for n, m in (("G", G), ("D", D), ("R", R), ("S", S))})
+            out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0], opts[1],
+                                opts[2], opts[3], pb["style"].float().numpy(), B, 128, net_loss.hinge, 1, 1, None, 10, "",
+                                fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False, **kw)
+            res[mode] = (np.array(out, np.float64), {n: (m.store.grad.clone(), m.store.flat.clone()) for n, m in models.items()})
     finally:
-        lib().sg_debug_set_splitk(-1)
+        ops.set_deterministic(False)
     sa, ga = res["default"]
     sb, gb = res["reference"]
+    assert sb[12] > 0.05 and sb[11] > 0.05, "fixture lost its conditioning: %r" % (sb[11:13],)
     assert np.all(np.abs(sa - sb) <= 1e-5 * np.maximum(1.0, np.abs(sb))), (sa, sb)
     for n in ("D", "R", "S", "G"):
         (da, wa), (db, wb) = ga[n], gb[n]
         scale = db.abs().max().item()
-        # fp32 summation order differs between the schedules; with gradient balancing G's upstream divides by a small std
-        tol = 5e-2 if n == "G" else 2e-4
-        assert (da - db).abs().max().item() <= tol * scale, "%s gradients: %.3e vs scale %.3e" % (n, (da - db).abs().max().item(), scale)
+        # fp32 summation order is all that differs between the schedules
+        assert (da - db).abs().max().item() <= 1e-3 * scale, "%s gradients: %.3e vs scale %.3e" % (n, (da - db).abs().max().item(), scale)
         assert (wa - wb).abs().max().item() <= 5e-4, n
 
 
@@ -257,3 +248,26 @@ def test_device_prefetcher_matches_the_host_loader(dev, tmp_path):
         assert np.array_equal(lab_d, lab_h)
         assert np.array_equal(im_d.cpu().numpy(), im_h), "GPU-side normalisation must be bit-identical to the numpy expression"
     pre.close()
+    # The loader shares the global `random` / `np.random` streams with train_step's fake-label draw and main.py's style
+    # draw (data_utils.py:386-392).  Two seeded runs that interleave those draws with next(prefetcher) must see the same
+    # batches AND the same fake labels (a generator pulled from a background thread interleaves by timing).
+    from scrabble_gan_amd import data_utils as DU
+    words = DU.synthetic_random_words(3, 20, seed=1)
+
+    def run():
+        random.seed(11)
+        np.random.seed(11)
+        pf = data_io.DevicePrefetcher(data_io.load_prepare_data((32, 160, 1), 5, str(tmp_path) + "/", cv, 3, raw=True), dev, depth=3)
+        seen = []
+        for i in range(8):
+            picks = random.choices(range(100), k=3)                  # main.py's style draw
+            im, lab = next(pf)
+            idx, fl = DU.draw_fake_labels(words, 3, 4)               # train_step's draw
+            if i % 3 == 0:
+                import time
+                time.sleep(0.02)                                     # give a racing thread every chance
+            seen.append((picks, im.cpu().numpy().tobytes(), lab.tobytes(), idx, fl.tobytes()))
+        pf.close()
+        return seen
+
+    assert run() == run()

@@ -161,6 +161,15 @@ int sg_bias_grad(const float* dy, float* db, long M, int N, void* stream);
  * (resnet_ops.py:105-114) */
 int sg_avgpool2_add_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C, void* stream);
 int sg_avgpool2_bwd(const float* dout, float* dx, int B, int H, int W, int C, void* stream);   /* H,W of dx */
+/* The same backward (resnet_ops.py:105-106 under the tapes of data_utils.py:449-468) writing the bf16 / fp8 OPERAND COPIES of dx
+ * directly instead of dx itself (configs c3 / c5: dx feeds only conv2's weight-grad and data-grad launches, which read operand
+ * copies): dx16 = bf16(0.25 dout[b,y/2,x/2,c]) and dx16_scaled = bf16(rowscale[b] * that) (each nullable, rowscale nullable);
+ * fp8: dx_e4m3 and dx_e5m2 (rowscale folded in; each nullable) with per-tensor scales 448 / amax, 57344 / amax, where
+ * amax_dout = {max |dout|, max |rowscale dout|} from sg_amax2_f32 and amax_dx[0..1] receives 0.25 * those.  Bit-identical
+ * to sg_avgpool2_bwd followed by sg_cvt_bf16 / sg_cvt_fp8_grad.  C % 8 == 0. */
+int sg_avgpool2_bwd_bf16(const float* dout, void* dx16, void* dx16_scaled, const float* rowscale, int B, int H, int W, int C, void* stream);
+int sg_avgpool2_bwd_fp8(const float* dout, void* dx_e4m3, void* dx_e5m2, const float* rowscale, const float* amax_dout, float* amax_dx,
+                        int B, int H, int W, int C, void* stream);
 int sg_add(const float* a, const float* b, float* out, long n, void* stream);
 int sg_relu_mask(const float* dy, const float* ref, float* dx, long n, void* stream);          /* dx = ref>0 ? dy : 0 */
 int sg_tanh_bwd(const float* y, const float* dy, float* dx, long n, void* stream);             /* net_architecture.py:289 */

@@ -156,6 +156,7 @@ extern "C" int sg_cvt_bf16_bias(const float* x, void* out, void* out_plain, long
   if (!x || !out || !dbias || M < 0 || C <= 0 || (C & 7) || (rowscale && rows_per_sample <= 0)) return SG_ERR_ARG;
   if (M == 0) return SG_OK;
   long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
+  if (sg_deterministic()) r = M;              // one workgroup, one adder per column (slow: a reproducibility mode)
   const int rpb = (int)(r < 32 ? 32 : r);
   hipLaunchKernelGGL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, (u16*)out_plain, M, C,
                      rowscale, rows_per_sample, dbias, rpb);
@@ -1229,6 +1230,7 @@ static int sg2_launch_wgrad(SgWgrad2Args a, long M, hipStream_t s) {
     if (t < best) { best = t; nchunks = cc; }
   }
   if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
+  if (sg_deterministic()) nchunks = 1;        // one adder per dW address (the 64 x 64 config's two k-groups: see the entry points)
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + 63) / 64 * 64;
   nchunks = (M + mchunk - 1) / mchunk;
@@ -1267,7 +1269,7 @@ extern "C" int sg_conv2d_bwd_weight_bf16v2(const void* x16, const void* dy16, fl
   hipStream_t s = (hipStream_t)stream;
   if (Cin % 256 == 0 && Cout % 256 == 0) return sg2_launch_wgrad<256, 256>(a, M, s);
   if (Cout % 256 == 0) return sg2_launch_wgrad<64, 256>(a, M, s);
-  if (Cin == 64 && Cout == 64) return sg2_launch_wgrad<64, 64>(a, M, s);
+  if (Cin == 64 && Cout == 64 && !sg_deterministic()) return sg2_launch_wgrad<64, 64>(a, M, s);   // (two k-groups add into one address)
   return SG_ERR_UNSUPPORTED;
 }
 
@@ -1292,6 +1294,7 @@ extern "C" int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void
   hipStream_t s = (hipStream_t)stream;
   if (Cout % 256 == 0 && Cin % 256 == 0) return sg2_launch_wgrad<256, 256, true>(a, M, s);
   if (Cin % 256 == 0) return sg2_launch_wgrad<64, 256, true>(a, M, s);
+  if (sg_deterministic()) return SG_ERR_UNSUPPORTED;
   return sg2_launch_wgrad<64, 64, true>(a, M, s);
 }
 

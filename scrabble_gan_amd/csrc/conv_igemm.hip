@@ -355,6 +355,7 @@ static int g_split_override = -1;   // tuning/debug: -1 = heuristic, 1 = never s
 extern "C" void sg_debug_set_splitk(int n) { g_split_override = n; }
 extern "C" void sg_debug_set_splitk_v2(int n);          // conv_bf16v2.hip: the second-generation kernels' own override
 static int g_deterministic = 0;
+bool sg_deterministic() { return g_deterministic != 0; }
 extern "C" int sg_set_deterministic(int on) {
   const int prev = g_deterministic;
   g_deterministic = on ? 1 : 0;

@@ -290,6 +290,7 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
       nchunks = cc;
     }
   }
+  if (sg_deterministic()) nchunks = 1;        // one adder per dW (and bias-gradient) address: fixed summation order
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;
@@ -446,7 +447,7 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
   // (~90 ns each), so the adder count per address bounds this kernel on small inputs while large inputs want the parallelism
   const long total_rows = (long)a.Bn * a.Hg;
   long nb = total_rows < 512 ? total_rows : 512;
-  if (nb < 1) nb = 1;
+  if (nb < 1 || sg_deterministic()) nb = 1;      // (deterministic mode: one workgroup, one adder per address)
   const int rpb = (int)((total_rows + nb - 1) / nb);
   const int grid = (int)((total_rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), lds, s, a, rpb, dy0, nrows, dx0, span);

@@ -268,6 +268,7 @@ int sg_launch_wgrad_bf16(const SgWgradArgs& a_in, hipStream_t s) {
     const double loss = (double)((W + 255) / 256) * 256.0 / (double)W * (1.0 + 0.004 * cc);
     if (loss < best) { best = loss; nchunks = cc; }
   }
+  if (sg_deterministic()) nchunks = 1;
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + 31) / 32 * 32;
   nchunks = (M + mchunk - 1) / mchunk;

@@ -17,7 +17,7 @@
 // One fragment set (48 registers beside 128 accumulators), the next step's reads issued right behind the current MFMAs;
 // two 64 KB stages; the DMAs of tile t+2 issued behind the barrier of tile t (a whole tile of lead).
 // Workgroup = one (tap, 256-channel c-tile, 256-channel n-tile) x one chunk of pixels; partial sums meet in dW through float
-// atomics, or -- deterministic mode -- are written to a workspace slab per chunk and summed in fixed order.
+// atomics; deterministic mode (sg_set_deterministic) runs ONE chunk per (tap, tile): one adder per address.
 #include "sg_conv.h"
 #include <stdlib.h>
 
@@ -271,6 +271,7 @@ extern "C" int sg_conv2d_bwd_weight_fp8(const void* x8, const float* amax_x, con
     if (t < best) { best = t; nchunks = cc; }
   }
   if (wg_env > 0) nchunks = wg_env < max_chunks ? wg_env : max_chunks;
+  if (sg_deterministic()) nchunks = 1;
   long mchunk = (M + nchunks - 1) / nchunks;
   mchunk = (mchunk + W8_PIX - 1) / W8_PIX * W8_PIX;
   nchunks = (M + mchunk - 1) / mchunk;
@@ -400,6 +401,7 @@ extern "C" int sg_cvt_fp8_grad(const float* x, void* out_e5m2, void* out_e4m3, l
   if (!x || !out_e5m2 || !amax2 || M < 0 || C <= 0 || (C & 7) || (rowscale && rows_per_sample <= 0)) return SG_ERR_ARG;
   if (M == 0) return SG_OK;
   long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
+  if (sg_deterministic() && dbias) r = M;     // one workgroup, one adder per column (slow: a reproducibility mode)
   const int rpb = (int)(r < 32 ? 32 : r);
   hipLaunchKernelGGL(k_cvt_fp8_grad, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out_e5m2,
                      (uint2*)out_e4m3, M, C, rowscale, rows_per_sample, amax2, dbias, rpb);

@@ -333,11 +333,12 @@ extern "C" int sg_bias_grad(const float* dy, float* db, long M, int N, void* str
     // <= 256 workgroups: every workgroup ends in one float atomic per column, and same-address atomics serialise
     // (~90 ns each: 1024 adders per column cost more than the whole sweep)
     long r = (M + 511) / 512;
+    if (sg_deterministic()) r = M;          // one workgroup: one adder per column, fixed summation order
     const int rpb = (int)(r < 16 ? 16 : r);
     hipLaunchKernelGGL(k_bias_grad_v4, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
     return sg_launch_status();
   }
-  const int rpb = 1024;
+  const int rpb = sg_deterministic() ? (int)(M < 1 ? 1 : M) : 1024;
   hipLaunchKernelGGL(k_bias_grad, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
   return sg_launch_status();
 }

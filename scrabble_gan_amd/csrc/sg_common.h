@@ -21,6 +21,11 @@ static inline int sg_launch_status() {
   return hipGetLastError() == hipSuccess ? SG_OK : SG_ERR_LAUNCH;
 }
 
+// sg_set_deterministic (conv_igemm.hip): when on, no convolution launch lets two workgroups add into the same output address
+// -- forward / data-grad launches are not cut along the reduction, weight-grad launches run ONE pixel chunk per
+// (tap, c-tile, n-tile), so every dW element has exactly one adder and its summation order is fixed.
+bool sg_deterministic();
+
 static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)

@@ -120,6 +120,7 @@ class _Model:
 
     @staticmethod
     def _fold(S):
+        ops.side_join()                  # the weight gradients of the sweep (queued on the side stream) are complete from here on
         if isinstance(S, nn.AppliedSNStore):
             S.fold()
 
@@ -241,6 +242,7 @@ class _DownTrunk:
                     d = nn.nonlocal_bwd(nlc, d, sigma, dsig, dnlw, wscale=wscale)
             d = nn.block_down_bwd(c, d, S, n, i == len(self.names) - 1, want_dx or i > 0, want_dw, wscale=wscale)
             if on_block_done is not None:
+                ops.side_join()          # this block's weight gradients (side stream) before their range is handed out
                 lo = S._off[n + ".conv1.w"]
                 hi = S._off[self.names[i + 1] + ".conv1.w"] if i + 1 < len(self.names) else self.end_offset(S)
                 on_block_done(lo, hi)

@@ -217,7 +217,9 @@ def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
         c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
         xp = ops.avgpool2_add_fwd(x)                                                          # pooled block input
         out = ops.avgpool2_add_fwd(c2)                                                        # :105-106
-        ops.conv2d_fwd(xp, p[pre + ".short.w"], p[pre + ".short.b"], out=out, accum=True)     # :109-114, pooled first
+        ops.conv2d_fwd(xp, p[pre + ".short.w"], p[pre + ".short.b"], out=out, accum=True, want16=True)     # :109-114, pooled first
+        # (want16: in bf16 mode the launch that completes the block's output also writes its bf16 twin -- the next block's conv
+        #  operand -- instead of a conversion sweep over the finished tensor)
     else:
         c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
         s = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])
@@ -230,17 +232,25 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     x, c1, xp = ctx
     p, g = S.p, S.g
     H, W = x.shape[1], x.shape[2]
-    d_c2 = dout if is_last else ops.avgpool2_bwd(dout)          # gradient of conv2's output (and of the 1x1 output when it pools last)
     pooled_short = xp is not None
-    if want_dw:
-        ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
-        if pooled_short:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
+    if want_dw and pooled_short:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
+        with ops.side_stream(xp, dout, wscale):
             ops.conv2d_bwd_weight(xp, dout, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
-        else:
-            ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
+    if is_last:
+        d_c2 = dout                  # gradient of conv2's output (and of the 1x1 output when it pools last)
+    elif pooled_short:               # only conv2's launches read it: low-precision modes write their operand copies directly
+        d_c2 = ops.avgpool2_bwd_operands(dout, wscale, want_dw)
+    else:
+        d_c2 = ops.avgpool2_bwd(dout)
+    if want_dw:          # (weight gradients are leaves of the sweep: side stream, see ops.side_stream)
+        with ops.side_stream(c1, x, d_c2, wscale):
+            ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
+            if not pooled_short:
+                ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=True)
     if want_dw:
-        ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
+        with ops.side_stream(x, d_c1, wscale):
+            ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
     if not want_dx:
         return None
     if pooled_short:

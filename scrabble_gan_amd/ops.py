@@ -114,6 +114,63 @@ def _stream() -> int:
     return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
+# ---- side stream for the weight-gradient launches -------------------------------------------------------------------
+# Weight gradients are LEAVES of a backward sweep: nothing reads dW before the sweep's all-reduce / optimizer update, while the
+# data-grad chain is sequentially dependent.  In fp32 mode they are queued on a second HIP stream (ordered after the kernel
+# that produced their gradient operand by an event), so the tail of a data-grad launch -- the last, partly filled round of
+# workgroups over the 256 CUs, a third of the time of a 4x20 layer at the 8-way shard batch -- overlaps weight-grad
+# workgroups instead of idling (the fp32 kernels keep 2-3 workgroups per CU resident, so two launches share a CU).  Off when
+# kernel timing is active (HIP-event brackets would measure overlapped launches), in deterministic mode, and in bf16 / fp8
+# modes (operand copies made on one stream are read on the other).  SG_SIDE_WGRAD=0 disables it.
+SIDE_WGRAD = _os.environ.get("SG_SIDE_WGRAD", "1") == "1"
+_SIDE = {"stream": None, "dirty": False}
+
+
+def side_enabled() -> bool:
+    return SIDE_WGRAD and PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32"
+
+
+class side_stream:
+    """with ops.side_stream(t1, t2, ...): the launches inside run on the side stream, after everything queued so far on the
+    main stream (in particular the producers of t1, t2, ... -- tensors the side launches read: their memory is not handed out
+    again before the side stream is done with them).  A no-op context when side_enabled() is False."""
+
+    def __init__(self, *inputs):
+        self.on = side_enabled()
+        self.inputs = inputs
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        if _SIDE["stream"] is None:
+            _SIDE["stream"] = torch.cuda.Stream()
+        side = _SIDE["stream"]
+        self.main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        side.wait_event(ev)
+        for t in self.inputs:
+            if t is not None:
+                t.record_stream(side)
+        torch.cuda.set_stream(side)
+        _SIDE["dirty"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.set_stream(self.main)
+        return False
+
+
+def side_join() -> None:
+    """The main stream waits for everything queued on the side stream (called before gradients are exchanged / applied)."""
+    if _SIDE["dirty"]:
+        ev = torch.cuda.Event()
+        ev.record(_SIDE["stream"])
+        torch.cuda.current_stream().wait_event(ev)
+        _SIDE["dirty"] = False
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -225,9 +282,84 @@ def grad_operand_fp8(dy: torch.Tensor, sample_scale, want_colsum: bool):
                  _p(amax2), _p(colsum), _stream())
         if out4 is not None:
             _TWINS[k4] = (dy, out4, amax2[0:1])
-        e = (dy, sample_scale, out5, amax2[1:2], colsum)
+        e = (dy, sample_scale, out5, amax2[1:2], colsum, amax2)
         _TWINS[key] = e
     return e[2], e[3], e[4]
+
+
+def _amax2_of(dy: torch.Tensor, sample_scale) -> torch.Tensor:
+    """Device pair {max |dy|, max |sample_scale dy|}: from the gradient's fp8 operand entry when it has one, else one read sweep."""
+    sptr = 0 if sample_scale is None else sample_scale.data_ptr()
+    e = _TWINS.get((dy.untyped_storage().data_ptr(), "g8", sptr, dy.storage_offset(), dy.numel()))
+    if e is not None:
+        return e[5]
+    key = (dy.untyped_storage().data_ptr(), "a2", sptr, dy.storage_offset(), dy.numel())
+    e = _TWINS.get(key)
+    if e is None:
+        _chk(dy, sample_scale)
+        amax2 = torch.zeros(2, device=dy.device)
+        rows = (dy.numel() // sample_scale.numel()) if sample_scale is not None else 4
+        with _hbm("cvt_fp8", dy):
+            call("sg_amax2_f32", _p(dy), dy.numel(), _p(sample_scale), rows, _p(amax2), _stream())
+        e = (dy, amax2)
+        _TWINS[key] = e
+    return e[1]
+
+
+def _grad_colsum(dy: torch.Tensor, sample_scale) -> torch.Tensor:
+    """fp32 column sums of sample_scale[b] * dy[b] (a bias gradient), from whichever operand entry of the gradient holds them."""
+    sptr = 0 if sample_scale is None else sample_scale.data_ptr()
+    base = (dy.untyped_storage().data_ptr(), dy.storage_offset(), dy.numel())
+    e = _TWINS.get((base[0], "g8", sptr, base[1], base[2]))
+    if e is not None and e[4] is not None:
+        return e[4]
+    return grad_operand(dy, sample_scale, True)[1]
+
+
+GHOST_NAN = _os.environ.get("SG_GHOST_NAN", "0") == "1"      # tests: poison the never-written fp32 tensors behind operand-only results
+
+
+def avgpool2_bwd_operands(dout: torch.Tensor, wscale=None, want_dw: bool = True) -> torch.Tensor:
+    """The gradient of a ResNetBlockDown's conv2 output, d_c2 = avgpool2_bwd(dout) [B,2Ho,2Wo,C], for its two consumers -- conv2's
+    weight-grad and data-grad.  bf16 / fp8 modes with a conv2 (C -> C, 3x3) that runs on the second-generation kernels: ONE kernel
+    reads dout and writes the operand copies those launches read (plain + per-sample-scaled bf16, or e4m3 + e5m2 with their amax
+    scalars); the returned fp32 tensor is a NEVER-WRITTEN handle that carries the copies through the twin registry (no fp32
+    d_c2 in HBM: 2-4 B/element written instead of 4 written + 8 re-read by amax / conversion sweeps).  The bias gradient of
+    conv2 (= column sums of d_c2 = column sums of dout) comes from dout's own operand entry.  Otherwise: plain sg_avgpool2_bwd."""
+    B, Ho, Wo, C = dout.shape
+    H, W = 2 * Ho, 2 * Wo
+    use8 = _fp8_wgrad_ok(C, C, 3, 3, True) and _fp8_ok(C, C, 3, 3, True)
+    use16 = (not use8) and _v2_ok(C, C, 3, 3, True) and (C % 256 == 0 or (C == 64 and not DETERMINISTIC))
+    if not (use8 or use16) or C % 8:
+        return avgpool2_bwd(dout)
+    _chk(dout, wscale)
+    ghost = torch.empty(B, H, W, C, device=dout.device, dtype=torch.float32)
+    if GHOST_NAN:
+        ghost.fill_(float("nan"))
+    gp, n = ghost.untyped_storage().data_ptr(), ghost.numel()
+    sptr = 0 if wscale is None else wscale.data_ptr()
+    colsum = _grad_colsum(dout, wscale) if want_dw else None
+    if use16:
+        plain = torch.empty(ghost.shape, device=dout.device, dtype=torch.bfloat16)
+        scaled = torch.empty(ghost.shape, device=dout.device, dtype=torch.bfloat16) if (want_dw and wscale is not None) else None
+        with _hbm("pool", dout, plain, scaled):
+            call("sg_avgpool2_bwd_bf16", _p(dout), plain.data_ptr(), None if scaled is None else scaled.data_ptr(), _p(wscale), B, H, W, C, _stream())
+        _twin_put(ghost, plain)
+        if want_dw:
+            _TWINS[(gp, sptr, 0, n)] = (ghost, wscale, plain if scaled is None else scaled, colsum)
+    else:
+        a2 = _amax2_of(dout, wscale)
+        out4 = torch.empty(ghost.shape, device=dout.device, dtype=torch.uint8)
+        out5 = torch.empty(ghost.shape, device=dout.device, dtype=torch.uint8) if want_dw else None
+        amax_dx = torch.empty(2, device=dout.device)
+        with _hbm("pool", dout, out4, out5):
+            call("sg_avgpool2_bwd_fp8", _p(dout), out4.data_ptr(), None if out5 is None else out5.data_ptr(), _p(wscale), _p(a2), _p(amax_dx),
+                 B, H, W, C, _stream())
+        _TWINS[(gp, "fp8", False, 0, n)] = (ghost, out4, amax_dx[0:1])
+        if want_dw:
+            _TWINS[(gp, "g8", sptr, 0, n)] = (ghost, wscale, out5, amax_dx[1:2], colsum, amax_dx)
+    return ghost
+
 
 
 def packed_filter_fp8(w: torch.Tensor, kind: str):
@@ -248,9 +380,18 @@ def packed_filter_fp8(w: torch.Tensor, kind: str):
     return out, amax
 
 
+DETERMINISTIC = False
+
+
 def set_deterministic(on: bool) -> None:
-    """on: force every conv launch -- first- and second-generation kernels, fp32 / bf16 / fp8 -- to one workgroup per output
-    tile (no split reductions / float atomics in the forward and data-grad kernels).  off: the default CU-quantum tail split."""
+    """on: every convolution launch -- first- and second-generation kernels, fp32 / bf16 / fp8 -- runs with ONE adder per output
+    address: forward / data-grad launches are not cut along the reduction (a sample's activations no longer depend on the
+    batch it is launched in), weight-grad launches run one pixel chunk per (tap, tile) and the fused / separate bias-gradient
+    column sums one workgroup, so dW and db have a fixed summation order (bitwise reproducible run to run).  Still
+    float-atomic in this mode: BatchNorm's per-sample dgamma / dbeta partials, the filter bank's dz, the attention key sweep
+    at small batch, spectral-norm's power iteration.  off: the default CU-quantum tail split and pixel chunking."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
     lib().sg_set_deterministic(1 if on else 0)
 
 
@@ -524,7 +665,7 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
         with _timed("wgrad_fp8", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, False, ("wgrad", B, H, W, Cin, Cout, kh)):
             call("sg_conv2d_bwd_weight_fp8", x8.data_ptr(), _p(ax), dy8.data_ptr(), _p(ady), _p(dw), B, H, W, Cin, Cout, kh, kw, int(same), _stream())
         return
-    if USE_V2 and _low() and (same or kh * kw == 1) and ((Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)):
+    if USE_V2 and _low() and (same or kh * kw == 1) and ((Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64 and not DETERMINISTIC)):
         # second-generation path: bf16 operands by DMA; the per-sample factors are folded into dy's bf16 copy, whose
         # conversion sweep also yields the bias gradient (fp32 column sums) and, if missing, the plain twin for the data-grad
         x16 = bf16_of(x)
@@ -590,7 +731,7 @@ def conv2d_transpose_bwd_weight(x, dy, dw, stride=(2, 2)):
     kh, kw, Cout, wc = dw.shape
     assert wc == Cin
     sh, sw = stride
-    if USE_V2 and _low() and Cin % 64 == 0 and Cout % 64 == 0 and H * W >= 64:
+    if USE_V2 and _low() and Cin % 64 == 0 and Cout % 64 == 0 and H * W >= 64 and (Cin % 256 == 0 or not DETERMINISTIC):
         x16, dy16 = bf16_of(x), bf16_of(dy)
         with _timed("wgrad", 2.0 * B * H * W * kh * kw * Cin * Cout, False, ("convT_wgrad", B, H, W, Cin, Cout, kh)):
             call("sg_conv2d_transpose_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), _p(dw), B, H, W, Cin, Cout, kh, kw, sh, sw, _stream())

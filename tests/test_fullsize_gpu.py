@@ -292,3 +292,70 @@ def test_deterministic_mode_covers_both_kernel_generations(dev, mode):
         ops.set_deterministic(False)
         ops.F32_V2_MIN_TILES = old_min
         ops.set_conv_dtype("f32")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp8"])
+def test_deterministic_weight_gradient(dev, mode):
+    """sg_set_deterministic(1) also fixes the summation order of dW and the bias gradient: one pixel chunk per
+    (tap, tile) and one workgroup for the column sums, i.e. ONE adder per address -- two launches on the same operands, adding
+    into a NON-zero gradient buffer (the accumulate contract), give bitwise identical results, on the MFMA kernels of every mode
+    and on the thin first-layer kernel.  The default launch of the same shape cuts the pixels into chunks that meet through
+    float atomics; it must agree with the deterministic result to fp32 rounding (1e-5 of max|dW|; bf16 / fp8: same operands)."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(17)
+    try:
+        ops.set_conv_dtype(mode)
+        for (B, H, W, Cin, Cout, k) in ((40, 4, 20, 256, 256, 3), (24, 8, 40, 64, 512, 1), (16, 32, 160, 1, 64, 3)):
+            x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+            dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+            sc = torch.rand(B, device=dev, generator=g) + 0.5
+            base_w = torch.randn(k, k, Cin, Cout, device=dev, generator=g)
+            base_b = torch.randn(Cout, device=dev, generator=g)
+            res = []
+            for det in (True, True, False):
+                ops.new_step()
+                ops.set_deterministic(det)
+                dw, db = base_w.clone(), base_b.clone()
+                ops.conv2d_bwd_weight(x, dy, dw, relu_in=True, db=db, sample_scale=sc)
+                res.append((dw, db))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (mode, Cin, Cout)
+            inc = (res[0][0] - base_w).abs().max().item()
+            assert (res[0][0] - res[2][0]).abs().max().item() <= 1e-5 * inc + 1e-6, (mode, Cin, Cout)
+            assert (res[0][1] - res[2][1]).abs().max().item() <= 1e-5 * (res[0][1] - base_b).abs().max().item() + 1e-5
+    finally:
+        ops.set_deterministic(False)
+        ops.set_conv_dtype("f32")
+
+
+@pytest.mark.parametrize("mode,C", [("bf16", 512), ("bf16", 64), ("fp8", 512), ("fp8", 1024)])
+def test_pool_backward_operand_copies_are_bit_identical(dev, mode, C):
+    """ops.avgpool2_bwd_operands (sg_avgpool2_bwd_bf16 / _fp8: conv2's gradient operands written straight from the pooled
+    gradient, no fp32 tensor in HBM) against the unfused path (sg_avgpool2_bwd, then the conversion sweeps): the plain and the
+    per-sample-scaled copies and the fp8 amax scalars must be BIT-identical (0.25 x is exact); the bias gradient (column sums
+    taken over dout instead of over its 4x replication) agrees to 2e-5."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(C)
+    B, Ho, Wo = 24, 8, 40
+    dout = torch.randn(B, Ho, Wo, C, device=dev, generator=g) * torch.rand(B, 1, 1, 1, device=dev, generator=g)
+    sc = torch.rand(B, device=dev, generator=g) * 2 - 0.5
+    try:
+        ops.set_conv_dtype(mode)
+        d = ops.avgpool2_bwd(dout)
+        gh = ops.avgpool2_bwd_operands(dout, sc, True)
+        assert torch.isnan(gh).all(), "the handle must not be written (tests poison it: ops.GHOST_NAN)"
+        if mode == "bf16":
+            t_u, cs_u = ops.grad_operand(d, sc, True)
+            t_f, cs_f = ops.grad_operand(gh, sc, True)
+            assert torch.equal(t_u, t_f) and torch.equal(ops.bf16_of(d), ops.bf16_of(gh))
+        else:
+            o5_u, a5_u, cs_u = ops.grad_operand_fp8(d, sc, True)
+            o5_f, a5_f, cs_f = ops.grad_operand_fp8(gh, sc, True)
+            (o4_u, a4_u), (o4_f, a4_f) = ops.fp8_of(d), ops.fp8_of(gh)
+            assert torch.equal(o5_u, o5_f) and torch.equal(o4_u, o4_f) and a5_u.item() == a5_f.item() and a4_u.item() == a4_f.item()
+        _close(cs_f, cs_u, 2e-5, "bias gradient from the pooled gradient")
+        # without per-sample factors the weight-grad operand IS the plain copy
+        gh2 = ops.avgpool2_bwd_operands(dout, None, True)
+        if mode == "bf16":
+            assert torch.equal(ops.grad_operand(gh2, None, True)[0], ops.bf16_of(d))
+    finally:
+        ops.set_conv_dtype("f32")

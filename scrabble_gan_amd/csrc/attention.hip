@@ -361,6 +361,10 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   }
   const long kblocks = (long)sg_cdiv(Nk, 32 * kw) * B;
   int zs = kblocks >= 320 ? 1 : (int)((512 + kblocks - 1) / kblocks);
+  // ... and until every SIMD has two waves (1 024 SIMDs): at the 8-way shard batch the generator site (16 x 1 280 keys) gave
+  // 320 workgroups of 2 waves -- 0.6 waves per SIMD, nothing to hide the LDS staging and the barriers behind
+  const long waves = kblocks * kw;
+  if (waves * zs < 2048 && (long)Nq * Nk >= (1L << 22)) zs = (int)((2048 + waves - 1) / waves);      // (large maps only)
   if (zs > 16) zs = 16;
   int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_QT) * AT_QT;        // whole LDS tiles per z slice
   zs = sg_cdiv(Nq, q_chunk);

@@ -807,7 +807,8 @@ class MyDiscriminatorModel(_Model):
         return {"theta": tp, "phi": pp, "g": gp, "o": op}
 
     def forward(self, x, nl=None):
-        p = self.store.p
+        S = self._pass_store()          # kernel_reg 'applied': spectrally normalised conv / dense kernels for this pass (net_architecture.py:425-450)
+        p = S.p
         x = _as_nhwc1(x, self.device)
         if nl is None:
             nl = nn.nonlocal_weights(32, self.nl_gen, torch.device("cpu"))
@@ -820,13 +821,13 @@ class MyDiscriminatorModel(_Model):
                 net, nlc = nn.nonlocal_fwd(net, self.pad_nl(nl, self.device), p["NL_B1.sigma"])
         last = ops.leaky_relu_fwd(net, 0.3)                         # the second LeakyReLU of :446
         h = ops.gap_fwd(last, relu=False)
-        return ops.dense_fwd(h, p["dense.w"]), (acts, nlc, net, last, h)
+        return ops.dense_fwd(h, p["dense.w"]), (acts, nlc, net, last, h, S)
 
     def backward(self, ctx, dlogits, want_dx: bool, want_dw: bool, wscale=None):
         if wscale is not None:
             raise NotImplementedError("shared backward sweeps are not wired for make_my_discriminator: pass share_backward=False")
-        p, g = self.store.p, self.store.g
-        acts, nlc, net4, last, h = ctx
+        acts, nlc, net4, last, h, S = ctx
+        p, g = S.p, S.g
         dlogits = dlogits.reshape(-1, 1).contiguous()
         if want_dw:
             ops.dense_bwd_weight(h, dlogits, g["dense.w"])
@@ -841,6 +842,8 @@ class MyDiscriminatorModel(_Model):
             gw = g["conv%d.w" % (i + 1)] if want_dw else torch.zeros_like(p["conv%d.w" % (i + 1)])
             gb = g["conv%d.b" % (i + 1)] if want_dw else torch.zeros_like(p["conv%d.b" % (i + 1)])
             d = nn.strided_conv_bwd(xin, p["conv%d.w" % (i + 1)], d, gw, gb, want_dx or i > 0)
+        if want_dw:
+            self._fold(S)
         return d
 
     def __call__(self, inputs, training=False):

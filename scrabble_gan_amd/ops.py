@@ -5,6 +5,7 @@ hand-written gfx950 kernel in libscrabble_hip.so.  All tensors are fp32, contigu
 GPU.  Nothing here falls back to torch math: a missing library or a failed launch raises."""
 from __future__ import annotations
 
+import os as _os
 from typing import Optional, Tuple
 
 import torch
@@ -196,7 +197,6 @@ def empty(*shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
 # Matrix-core operand type of the 3x3 / 1x1 convolutions: "f32" (v_mfma_f32_32x32x2_f32, the parity mode) or "bf16"
 # (v_mfma_f32_32x32x16_bf16 with fp32 accumulation: BASELINE config c3).  Tensors in HBM are fp32 either way.
 CONV_DTYPE = "f32"
-import os as _os
 # fp32 mode: let the data-grad launches of the >= 128-channel layers read a transposed filter copy (straight [K,N] loader
 # instead of the transposing one).  Measured on MI355X: no gain (129.7 vs 130.0 TF/s in-step), so it is off by default.
 TRANSPOSED_DGRAD_FILTERS = _os.environ.get("SG_DGRAD_WT", "0") == "1"

@@ -63,20 +63,18 @@ def test_c4_bucketed_step_against_oracle(NA, dev):
     check_step_against_calibrated_oracle(NA, dev, pb, "hinge", False, "c4_Lr5_Lf4", bucket_size=23)
 
 
-def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
-    """Config c3: global batch 256, L_r = L_f = 10, bf16 matrix-core convolutions (fp32 accumulation), against the same
-    step in fp32 mode (same weights, inputs and NonLocalBlock kernels).  Tolerances = bf16 operand rounding: 16 scalars
-    within 3e-2 * max(1, |fp32|); every network's flat gradient has cosine > 0.995 with the fp32 one (G: > 0.97, its
-    gradient crosses the data-grad sweeps of D, S and R); fake images within 2e-2."""
+def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None):
+    """One train_step at global batch B, L_r = L_f = 10, in fp32 mode and in `mode`, on identical weights, inputs and NonLocalBlock
+    kernels -> {mode: (16 scalars, {net: flat gradient}, fake images)}."""
     from scrabble_gan_amd import data_utils as DU, net_loss, nn, ops, optimizers
-    B, L = 256, 10
+    L = 10
     images, labels, my_imgs = DU.synthetic_batch(B, L, seed=3)
     words = DU.synthetic_random_words(10, 300, seed=3)
     fake = np.array(words[L - 1][:B], np.int32)
     res = {}
     try:
-        for mode in ("f32", "bf16"):
-            ops.set_conv_dtype(mode)
+        for md in ("f32", mode):
+            ops.set_conv_dtype(md)
             NA._model_counter[0] = 0                       # identical initial weights in both runs
             G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
             D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
@@ -87,17 +85,29 @@ def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
                 for k in m.store.names:
                     if k.endswith(".sigma"):
                         m.store.p[k].fill_(0.25)
+            if dense_scale is not None:                   # logits O(1): std(g_loss) is then not a difference of nearly equal numbers
+                for m in (D, S):
+                    m.store.p["dense.w"].mul_(dense_scale)
             g2 = torch.Generator().manual_seed(5)
             nl = {n: {k: v.to(dev) for k, v in nn.nonlocal_weights(64, g2, torch.device("cpu")).items()}
                   for n in ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")}
             x_f = G.forward(torch.from_numpy(my_imgs).to(dev), torch.from_numpy(fake).to(dev), nl["G.style"], nl["G.up"], training=False)[0]
             opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
             out = DU.train_step(0, 0, 1, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_imgs, B, 128,
-                                net_loss.hinge, 1, 0, words, 10, "", fake_labels=fake, nl=nl, verbose=False)
-            res[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}, x_f)
+                                net_loss.hinge, 1, int(balance), words, 10, "", fake_labels=fake, nl=nl, verbose=False)
+            res[md] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in (("G", G), ("D", D), ("R", R), ("S", S))}, x_f)
             del G, D, R, S, gan
     finally:
         ops.set_conv_dtype("f32")
+    return res
+
+
+def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
+    """Config c3: global batch 256, L_r = L_f = 10, bf16 matrix-core convolutions (fp32 accumulation), against the same
+    step in fp32 mode (same weights, inputs and NonLocalBlock kernels).  Tolerances = bf16 operand rounding: 16 scalars
+    within 3e-2 * max(1, |fp32|); every network's flat gradient has cosine > 0.995 with the fp32 one (G: > 0.97, its
+    gradient crosses the data-grad sweeps of D, S and R); fake images within 2e-2."""
+    res = _step_in_two_modes(NA, dev, 256, "bf16", False)
     s32, g32_, x32 = res["f32"]
     s16, g16, x16 = res["bf16"]
     assert np.all(np.isfinite(s16))
@@ -107,3 +117,34 @@ def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
         a, b = g32_[n].double(), g16[n].double()
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > (0.97 if n == "G" else 0.995), "%s: cosine %.5f" % (n, cos)
+
+
+def test_c5_fp8_step_at_the_bs64_shard_tracks_fp32(NA, dev):
+    """Config c5 at its 8-way shard size (global batch 512 -> 64 per GPU), L_r = L_f = 10, gradient balancing ON: fp8 forward /
+    data-grad (e4m3) and weight-grad (e4m3 x e5m2) launches of the >= 256-channel convolutions of G / D / S at their real
+    launch geometry (fused passes of 128 / 192 samples: 1 280 ... 7 680 output tiles, fp8 weight-grads over 61 440 ...
+    245 760 pixels), bf16 elsewhere, against the same step in fp32 mode.  D / S final Dense x 70 (logits O(1): balancing
+    divides by std(g_loss)).  e4m3 keeps 3 mantissa bits, e5m2 2: scalars within 0.2 * max(1, |fp32|), gradient cosines
+    D / S / R > 0.9, G > 0.8 (the bars of tests/test_fp8_gpu.py's toy-size step; measured values are written to
+    gpurun_out/c5_bs64_tracking.txt), fake images within 0.15."""
+    import os
+    res = _step_in_two_modes(NA, dev, 64, "fp8", True, dense_scale=70.0)
+    s32, g32_, x32 = res["f32"]
+    s8, g8, x8 = res["fp8"]
+    lines = ["scalars fp32 %s" % np.array2string(s32, precision=4), "scalars fp8  %s" % np.array2string(s8, precision=4),
+             "fake images max |fp8 - fp32| %.4f" % (x8 - x32).abs().max().item()]
+    cosines = {}
+    for n in ("D", "R", "S", "G"):
+        a, b = g32_[n].double(), g8[n].double()
+        cosines[n] = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        lines.append("%s gradient cosine %.5f  (|fp8| / |fp32| = %.4f)" % (n, cosines[n], float(b.norm() / (a.norm() + 1e-30))))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        open("gpurun_out/c5_bs64_tracking.txt", "w").write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    assert np.all(np.isfinite(s8)), s8
+    assert np.all(np.abs(s8 - s32) <= 0.2 * np.maximum(1.0, np.abs(s32))), (s8, s32)
+    assert (x8 - x32).abs().max().item() <= 0.15
+    for n in ("D", "R", "S", "G"):
+        assert cosines[n] > (0.8 if n == "G" else 0.9), "%s: cosine %.4f" % (n, cosines[n])

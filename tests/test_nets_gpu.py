@@ -296,7 +296,7 @@ def _rescale_kernels(model, P, gen):
     return P
 
 
-@pytest.mark.parametrize("which", ["discriminator", "generator"])
+@pytest.mark.parametrize("which", ["discriminator", "generator", "my_discriminator"])
 def test_kernel_reg_applied(dev, which):
     """kernel_reg = 'applied' (SURVEY Appendix C-3): every regularised kernel is divided by its one-step power-iteration
     sigma before it is used, forward AND backward (gradients flow through sigma, v^ and u^).  Checker: the oracle's
@@ -323,6 +323,28 @@ def test_kernel_reg_applied(dev, which):
             close(logits, ref, 1e-4, "logits with normalised kernels")
             # the normalisation really happened: the un-normalised forward differs
             assert (O.discriminator(x, {k: v.detach() for k, v in P.items()}, nlo) - ref).abs().max().item() > 1e-3
+            M.store.zero_grad()
+            dx = M.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
+            close(dx, xr.grad, 1e-3, "dx")
+            at = net_atol([v.grad for v in lv.values()])
+            for k, v in lv.items():
+                close(M.store.g[k], v.grad, 2e-3, "grad " + k, at)
+        elif which == "my_discriminator":        # (the conv / dense kernels of :425-450 carry kernel_regularizer too)
+            M = NA.make_my_discriminator("", (32, 160, 1), spectral_norm, vis_model=False)
+            P = _rescale_kernels(M, perturb(M, gen), gen)
+            B, W = 3, 64
+            x = torch.rand(B, 32, W, 1, generator=gen, dtype=torch.float64) * 2 - 1
+            nlo = O.init_nonlocal(32, gen)
+            nlg = {k: v.float() for k, v in nlo.items()}
+            up = torch.randn(B, generator=gen, dtype=torch.float64)
+            lv = leaves(P)
+            Pn = _oracle_sn(P, nn.sn_names(M.store), M.sn_gen.initial_seed())
+            xr = x.clone().requires_grad_(True)
+            ref = O.my_discriminator(xr, Pn, nlo)
+            (ref[:, 0] * up).sum().backward()
+            logits, ctx = M.forward(x.float().to(dev), nlg)
+            close(logits, ref, 1e-4, "logits with normalised kernels")
+            assert (O.my_discriminator(x, {k: v.detach() for k, v in P.items()}, nlo) - ref).abs().max().item() > 1e-3
             M.store.zero_grad()
             dx = M.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
             close(dx, xr.grad, 1e-3, "dx")

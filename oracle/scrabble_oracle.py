@@ -82,9 +82,14 @@ def avg_pool2(x: Tensor) -> Tensor:
     return _nhwc(F.avg_pool2d(_nchw(x), 2))
 
 
+MAXPOOL_HOOK = None    # tests only: callable(x, ph, pw) -> pooled tensor, sees every MaxPool2D site in call order
+
+
 def max_pool(x: Tensor, ph: int, pw: int) -> Tensor:
     """layers.MaxPool2D(pool_size=(ph,pw)) VALID, stride = pool (arch_ops.py:47,58;
     net_architecture.py:29,32,38,47)."""
+    if MAXPOOL_HOOK is not None:
+        return MAXPOOL_HOOK(x, ph, pw)
     return _nhwc(F.max_pool2d(_nchw(x), (ph, pw)))
 
 
@@ -297,13 +302,13 @@ def recognizer_probs(x: Tensor, p: Dict[str, Tensor], bn_training: bool = False)
         else:
             x_hat = (t - p[pre + ".mm"]) * torch.rsqrt(p[pre + ".mv"] + BN_EPS)
         return x_hat * p[pre + ".gamma"] + p[pre + ".beta"]
-    net = max_pool(torch.relu(conv2d(x, p["conv1.w"], p["conv1.b"])), 2, 2)
-    net = max_pool(torch.relu(conv2d(net, p["conv2.w"], p["conv2.b"])), 2, 2)
-    net = torch.relu(conv2d(net, p["conv3.w"], p["conv3.b"]))
-    net = max_pool(torch.relu(conv2d(net, p["conv4.w"], p["conv4.b"])), 2, 1)
-    net = bn(torch.relu(conv2d(net, p["conv5.w"], p["conv5.b"])), "bn5")
-    net = max_pool(bn(torch.relu(conv2d(net, p["conv6.w"], p["conv6.b"])), "bn6"), 2, 1)
-    net = torch.relu(conv2d(net, p["conv7.w"], p["conv7.b"], padding="valid"))
+    net = max_pool(relu(conv2d(x, p["conv1.w"], p["conv1.b"])), 2, 2)
+    net = max_pool(relu(conv2d(net, p["conv2.w"], p["conv2.b"])), 2, 2)
+    net = relu(conv2d(net, p["conv3.w"], p["conv3.b"]))
+    net = max_pool(relu(conv2d(net, p["conv4.w"], p["conv4.b"])), 2, 1)
+    net = bn(relu(conv2d(net, p["conv5.w"], p["conv5.b"])), "bn5")
+    net = max_pool(bn(relu(conv2d(net, p["conv6.w"], p["conv6.b"])), "bn6"), 2, 1)
+    net = relu(conv2d(net, p["conv7.w"], p["conv7.b"], padding="valid"))
     net = net.squeeze(1)                                                        # :52
     return torch.softmax(net @ p["dense.w"] + p["dense.b"], dim=-1)             # :55
 

@@ -196,6 +196,10 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         s_r, _ = S.forward(images, nl.get("S.real"))
         r_r, ctx_rr = R.forward(images, labels_t, il_r, L_r, training=True)
 
+    if DEBUG_KEEP is not None:                                      # (tests: the recognizer's ReLU / max-pool decisions)
+        DEBUG_KEEP["R_f"] = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
+        DEBUG_KEEP["R_r"] = R.slice_ctx(ctx_R, B, 2 * B) if (fuse and fuse_r) else ctx_rr
+
     # ---- losses, gradient balancing, statistics and the upstream gradients of all four targets (:418-442) ----
     mode = getattr(loss_fn, "mode", None)
     if mode is None:

@@ -247,7 +247,9 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
             ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
             if not pooled_short:
                 ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
-    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=True)
+    # (bf16 twin of d_c1 from the epilogue, unless both of its consumers -- conv1's weight-grad and data-grad -- read fp8 copies)
+    cin, cout = x.shape[-1], c1.shape[-1]
+    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True))
     if want_dw:
         with ops.side_stream(x, d_c1, wscale):
             ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)

@@ -122,8 +122,11 @@ def _stream() -> int:
 # workgroups over the 256 CUs, a third of the time of a 4x20 layer at the 8-way shard batch -- overlaps weight-grad
 # workgroups instead of idling (the fp32 kernels keep 2-3 workgroups per CU resident, so two launches share a CU).  Off when
 # kernel timing is active (HIP-event brackets would measure overlapped launches), in deterministic mode, and in bf16 / fp8
-# modes (operand copies made on one stream are read on the other).  SG_SIDE_WGRAD=0 disables it.
+# modes (operand copies made on one stream are read on the other), and for launches of more than SIDE_MAX_BATCH samples: measured
+# on MI355X (profiles/r03_side_stream.txt), per-GPU batch 16: 52.98 -> 52.04 ms / step (+1.8 %); batch 128: 346.1 -> 349.8 ms
+# (-1 %: the grids fill many rounds of the chip, two resident kernels only compete for L2).  SG_SIDE_WGRAD=0 disables it.
 SIDE_WGRAD = _os.environ.get("SG_SIDE_WGRAD", "1") == "1"
+SIDE_MAX_BATCH = int(_os.environ.get("SG_SIDE_MAX_BATCH", "96"))
 _SIDE = {"stream": None, "dirty": False}
 
 
@@ -137,7 +140,7 @@ class side_stream:
     again before the side stream is done with them).  A no-op context when side_enabled() is False."""
 
     def __init__(self, *inputs):
-        self.on = side_enabled()
+        self.on = side_enabled() and inputs[0].shape[0] <= SIDE_MAX_BATCH
         self.inputs = inputs
 
     def __enter__(self):

@@ -46,32 +46,54 @@ def make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=300.0, z_sca
     return dict(P=P, images=images, style=style, labels=labels, fake=fake, nl=nl, B=B, L_r=L_r, L_f=L_f)
 
 
-G_RELU_SITES = 16      # ReLU activation sites of one generator forward, in the oracle's call order: style encoder
-                       # B_style1..4 x (relu(x), relu(conv1)), relu before GAP, B1..B3 x (cbn1, cbn2), the final BN
+# ReLU / MaxPool2D sites of one oracle train_step in call order (O.train_step: G, D(x_f), S(x_f), R(x_f), D(real), S(style),
+# S(real), R(real)).  ReLU: G 16 (style encoder B_style1..4 x (relu(x), relu(conv1)), relu before GAP, B1..B3 x (cbn1, cbn2),
+# final BN), D / S 9 each (4 blocks x 2 + the one before GAP), R 7 (one per conv).  MaxPool: 2 per NonLocalBlock (phi, g), 4 per R.
+RELU_RANGE = {"G": (0, 16), "D_f": (16, 25), "S_f": (25, 34), "R_f": (34, 41), "D_r": (41, 50), "S_my": (50, 59), "S_r": (59, 68), "R_r": (68, 75)}
+POOL_RANGE = {"G": (0, 4), "D_f": (4, 6), "S_f": (6, 8), "R_f": (8, 12), "D_r": (12, 14), "S_my": (14, 16), "S_r": (16, 18), "R_r": (18, 22)}
+G_RELU_SITES = 16
 
 
-def run_oracle(pb, dtype, loss_name="hinge", balance=False, relu_sites=None, forced=None):
+def _windows(x, ph, pw):
+    B, H, W, C = x.shape
+    return x.reshape(B, H // ph, ph, W // pw, pw, C).permute(0, 1, 3, 5, 2, 4).reshape(B, H // ph, W // pw, C, ph * pw)
+
+
+def run_oracle(pb, dtype, loss_name="hinge", balance=False, relu_sites=None, forced=None, pool_sites=None, forced_pool=None):
     """-> (16 scalars, {net: {name: grad}}, {net: {name: post-update weight}}, fake images); pb is not modified.
-    relu_sites (list, optional): receives the PRE-activation tensor of each of the generator's G_RELU_SITES ReLU sites.
-    forced (list of bool tensors or None per site, optional): the counterfactual oracle -- at those sites the ReLU DECISION is
-    imposed (y = x * mask, so the backward mask follows) instead of taken from the sign of the fp64 pre-activation."""
-    calls = [0]
+    relu_sites / pool_sites (lists, optional): receive the PRE-activation tensor of every ReLU site / the input of every
+    MaxPool2D site of the step, in call order (RELU_RANGE / POOL_RANGE).
+    forced (dict site -> bool tensor) / forced_pool (dict site -> window-position tensor, the encoding of sg_maxpool_fwd):
+    the counterfactual oracle -- at those sites the DECISION is imposed (y = x * mask, resp. y = the chosen window element, so
+    the backward routing follows) instead of taken from the fp64 values."""
+    calls, pcalls = [0], [0]
 
     def hook(x):
         i = calls[0]
         calls[0] += 1
-        if i < G_RELU_SITES:
-            if relu_sites is not None:
-                relu_sites.append(x.detach().clone())
-            if forced is not None and forced[i] is not None:
-                return x * forced[i].to(x.dtype)
+        if relu_sites is not None:
+            relu_sites.append(x.detach().clone())
+        if forced is not None and forced.get(i) is not None:
+            return x * forced[i].to(x.dtype)
         return torch.relu(x)
 
-    O.RELU_HOOK = hook if (relu_sites is not None or forced is not None) else None
+    def pool_hook(x, ph, pw):
+        i = pcalls[0]
+        pcalls[0] += 1
+        if pool_sites is not None:
+            pool_sites.append((x.detach().clone(), ph, pw))
+        if forced_pool is not None and forced_pool.get(i) is not None:
+            return torch.gather(_windows(x, ph, pw), -1, forced_pool[i].long().unsqueeze(-1)).squeeze(-1)
+        return _windows(x, ph, pw).max(dim=-1).values
+
+    hooked = relu_sites is not None or forced is not None or pool_sites is not None or forced_pool is not None
+    O.RELU_HOOK = hook if hooked else None
+    O.MAXPOOL_HOOK = pool_hook if hooked else None
     try:
         return _run_oracle(pb, dtype, loss_name, balance)
     finally:
         O.RELU_HOOK = None
+        O.MAXPOOL_HOOK = None
 
 
 def _run_oracle(pb, dtype, loss_name, balance):
@@ -87,14 +109,14 @@ def _run_oracle(pb, dtype, loss_name, balance):
 
 def calibrate(pb, loss_name="hinge", balance=False):
     """fp64 reference + the per-tensor deviation of the oracle's own fp32 evaluation from it."""
-    sites64 = []
-    s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance, relu_sites=sites64)
+    sites64, pools64 = [], []
+    s64, g64, w64, x64 = run_oracle(pb, torch.float64, loss_name, balance, relu_sites=sites64, pool_sites=pools64)
     s32, g32, w32, x32 = run_oracle(pb, torch.float32, loss_name, balance)
     err32 = {n: {k: (g32[n][k].double() - v).abs().max().item() for k, v in g64[n].items()} for n in g64}
     l2err32 = {n: {k: (g32[n][k].double() - v).norm().item() for k, v in g64[n].items()} for n in g64}
     serr32 = [abs(a - b) for a, b in zip(s32, s64)]
     return dict(scalars=s64, grads=g64, weights=w64, x_f=x64, err32=err32, l2err32=l2err32, scalar_err32=serr32, x_err32=(x32.double() - x64).abs().max().item(),
-                relu_sites64=sites64)
+                relu_sites64=sites64, pool_sites64=pools64)
 
 
 def load_models(NA, pb, dev):
@@ -117,11 +139,13 @@ def load_models(NA, pb, dev):
     return models, gan, nlg
 
 
-def hip_relu_decisions(ctx_g):
-    """The ReLU decisions the HIP generator forward took, one bool tensor per site in the oracle's call order (G_RELU_SITES),
-    from the context train_step saved: the style encoder applies its ReLUs in the consumers' operand loaders (decision = sign
-    of the saved fp32 pre-activation), the up blocks and the final BatchNorm materialise relu(.) (decision = output > 0)."""
-    tctx, h, z, y, up_ctx, bctx, yb, img, S = ctx_g
+def hip_decisions(keep):
+    """The ReLU / max-pool decisions the HIP forward passes took, from the contexts train_step saved (DEBUG_KEEP):
+    -> ({relu site: bool tensor}, {pool site: uint8 window positions}) for the generator (its 16 ReLU sites) and the two
+    recognizer calls (7 ReLU + 4 MaxPool2D sites each), indexed as RELU_RANGE / POOL_RANGE.
+    The style encoder applies its ReLUs in the consumers' operand loaders (decision = sign of the saved fp32 pre-activation);
+    the up blocks, the final BatchNorm and the recognizer's convolutions materialise relu(.) (decision = output > 0)."""
+    tctx, h, z, y, up_ctx, bctx, yb, img, S = keep["ctx_g"]
     ctxs, net = tctx
     dec = []
     for (x, c1, _xp), _nl in ctxs:
@@ -132,4 +156,16 @@ def hip_relu_decisions(ctx_g):
         dec += [c1[1] > 0, c2[1] > 0]
     dec.append(yb > 0)
     assert len(dec) == G_RELU_SITES
-    return [d.cpu() for d in dec]
+    relu = {i: d.cpu() for i, d in enumerate(dec)}
+    pool = {}
+    for tag in ("R_f", "R_r"):
+        acts = keep[tag][0]
+        r0, p0 = RELU_RANGE[tag][0], POOL_RANGE[tag][0]
+        k = 0
+        for i, rec in enumerate(acts):
+            relu[r0 + i] = (rec["a"] > 0).cpu()
+            if "idx" in rec:
+                pool[p0 + k] = rec["idx"].cpu()
+                k += 1
+        assert k == 4 and len(acts) == 7
+    return relu, pool

@@ -425,7 +425,7 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
                             fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
     finally:
         DU.DEBUG_KEEP = None
-    hip_decisions = F.hip_relu_decisions(keep["ctx_g"])
+    hip_relu, hip_pool = F.hip_decisions(keep)
     del keep
     assert len(out) == 16 and out[10] == 1
     for i, (a, b) in enumerate(zip(out, ref_scalars)):
@@ -461,19 +461,22 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
                 # The exemption has to PROVE that claim: see the counterfactual oracle below.
                 n_out = int((diff > bound).sum().item())
                 flips.append("%s.%s: %d element(s) above the bound, max %.3e (bound %.3e)" % (net, k, n_out, err, bound))
-                if n_out > 64 or net != "G":
+                if n_out > 64 or net not in ("G", "R"):
                     bad.append("%s grad %s: |HIP-fp64| %.3e > bound %.3e at %d elements (oracle fp32 err %.3e, scale %.3e)" % (net, k, err, bound, n_out, e32, scale))
                 else:
-                    exempted.append((k, bound, at))
-    # ---- proof of the outlier exemption.  (1) Every ReLU decision of the HIP generator forward that differs from the fp64
-    # oracle's must sit within fp32 rounding of the boundary: |fp64 pre-activation| <= 2e-5 x the site's largest
-    # pre-activation (checked whether or not a tensor needed the exemption -- a decision that differs AWAY from zero is a
-    # wrong activation, not rounding).  (2) The fp64 oracle is re-evaluated with exactly those decisions imposed (the
-    # counterfactual: y = x * HIP's mask at the generator's 16 ReLU sites, backward mask included); against IT every exempted
-    # tensor must meet its calibrated bound at ALL elements.  An indexing error that touches <= 64 elements survives neither.
-    sites64 = cal["relu_sites64"]          # fp64 pre-activations of the generator's ReLU sites (recorded by the calibration run)
-    forced, n_flip = [], 0
-    for i, (pre, dec) in enumerate(zip(sites64, hip_decisions)):
+                    exempted.append((net, k, bound, at))
+    # ---- proof of the outlier exemption.  (1) Every ReLU / max-pool decision of the HIP generator and recognizer passes that
+    # differs from the fp64 oracle's must sit within fp32 rounding of the boundary: |fp64 pre-activation| (resp. the gap between
+    # the chosen window element and the window maximum) <= 2e-5 x the site's largest value (checked whether or not a tensor
+    # needed the exemption -- a decision that differs AWAY from the boundary is a wrong activation, not rounding).  (2) The fp64
+    # oracle is re-evaluated with exactly those decisions imposed (the counterfactual: y = x * HIP's mask at the 30 ReLU
+    # sites, y = HIP's window element at the 8 MaxPool2D sites, backward routing included); against IT every exempted tensor
+    # must meet its calibrated bound at ALL elements.  An indexing error that touches <= 64 elements survives neither.
+    # (Decisions inside D / S are not imposed: an outlier in their gradients is not exempted at all.)
+    sites64, pools64 = cal["relu_sites64"], cal["pool_sites64"]
+    forced, forced_pool, n_flip = {}, {}, 0
+    for i, dec in sorted(hip_relu.items()):
+        pre = sites64[i]
         assert pre.shape == dec.shape, (i, pre.shape, dec.shape)
         flip = dec != (pre > 0)
         nf = int(flip.sum().item())
@@ -483,19 +486,33 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
             flips.append("ReLU site %d: %d decision(s) differ from fp64, farthest pre-activation %.3e (limit %.3e)" % (i, nf, far, lim))
             if far > lim:
                 bad.append("ReLU site %d: a decision differs from the fp64 oracle at |pre-activation| %.3e > %.3e (not a rounding flip)" % (i, far, lim))
+            forced[i] = dec
         n_flip += nf
-        forced.append(dec if nf else None)
+    for i, idx in sorted(hip_pool.items()):
+        x64, ph, pw = pools64[i]
+        win = F._windows(x64, ph, pw)
+        assert win.shape[:-1] == idx.shape, (i, win.shape, idx.shape)
+        chosen = torch.gather(win, -1, idx.long().unsqueeze(-1)).squeeze(-1)
+        gap = win.max(dim=-1).values - chosen
+        nf = int((gap > 0).sum().item())
+        if nf:
+            far, lim = gap.max().item(), 2e-5 * x64.abs().max().item()
+            flips.append("MaxPool site %d: %d selection(s) differ from fp64, largest gap %.3e (limit %.3e)" % (i, nf, far, lim))
+            if far > lim:
+                bad.append("MaxPool site %d: a selection differs from the fp64 oracle by %.3e > %.3e (not a rounding flip)" % (i, far, lim))
+            forced_pool[i] = idx
+        n_flip += nf
     if exempted:
         if n_flip == 0:
-            bad.append("outliers in %s but NO ReLU decision of the generator differs from fp64: not a decision flip" % [k for k, _, _ in exempted])
+            bad.append("outliers in %s but NO ReLU / max-pool decision of G or R differs from fp64: not a decision flip" % [k for _, k, _, _ in exempted])
         else:
-            _, g_cf, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced)
-            for k, bound, at in exempted:
-                d_cf = (models["G"].store.g[k].detach().double().cpu() - g_cf["G"][k]).abs()
+            _, g_cf, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced, forced_pool=forced_pool)
+            for net, k, bound, at in exempted:
+                d_cf = (models[net].store.g[k].detach().double().cpu() - g_cf[net][k]).abs()
                 n_cf = int((d_cf > bound).sum().item())
-                flips.append("G.%s vs the counterfactual oracle (HIP's decisions imposed): max %.3e, %d element(s) above the bound %.3e" % (k, d_cf.max().item(), n_cf, bound))
+                flips.append("%s.%s vs the counterfactual oracle (HIP's decisions imposed): max %.3e, %d element(s) above the bound %.3e" % (net, k, d_cf.max().item(), n_cf, bound))
                 if n_cf:
-                    bad.append("G grad %s: %d outlier(s) remain against the counterfactual oracle (max %.3e > bound %.3e): not explained by the ReLU flips" % (k, n_cf, d_cf.max().item(), bound))
+                    bad.append("%s grad %s: %d outlier(s) remain against the counterfactual oracle (max %.3e > bound %.3e): not explained by the decision flips" % (net, k, n_cf, d_cf.max().item(), bound))
     # what the calibration looked like (kept by gpurun under gpurun_out/ for DESIGN.md)
     try:
         import os

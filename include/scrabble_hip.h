@@ -89,10 +89,14 @@ int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowsca
  * data-grad operand of the same gradient), dbias[c] += the fp32 column sums of the scaled values.  C % 8 == 0. */
 int sg_cvt_bf16_bias(const float* x, void* out, void* out_plain, long M, int C, const float* rowscale, long rows_per_sample,
                      float* dbias, void* stream);
+/* amax_y / amax_dx (nullable, 2 floats, zeroed by the caller; config c5): the epilogue also takes max |result| (element 0) and
+ * max |amax_rowscale[b] * result| (element 1; amax_rowscale nullable [B] = no factor) with atomicMax while it writes the result:
+ * the per-tensor scales of the fp8 launches that read this result next, without a separate amax sweep over it. */
 int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
-                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_y, void* stream);
 int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, const void* mask16, float* dx, void* dx16,
-                              int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+                              int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_dx,
+                              const float* amax_rowscale, void* stream);
 /* dw [kh,kw,Cin,Cout] (fp32) += weight gradient of the SAME stride-1 convolution from bf16 operands x16 [B,H,W,Cin] and
  * dy16 [B,H,W,Cout] (tape of d_loss / s_loss / g_final, data_utils.py:449-468; per-sample factors already folded into dy16 by
  * sg_cvt_bf16).  flags: SG_RELU_IN on x16.  No bias gradient (sg_bias_grad).  SG_ERR_UNSUPPORTED unless (Cin % 64 == 0 and
@@ -112,15 +116,17 @@ int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void* dy16, flo
  *      relu != 0 applies max(.,0) first (n % 8 == 0).  sg_pack_filter_fp8: as sg_pack_filter_bf16, bytes instead of bf16.
  *      sg_conv2d_fwd_fp8 / sg_conv2d_bwd_data_fp8: contracts of the bf16v2 entry points (resnet_ops.py:98,103 call sites
  *      of the D-shaped trunks); SG_RELU_IN is not accepted (fold it into sg_cvt_fp8); SG_ERR_UNSUPPORTED unless reduction
- *      channels % 128 == 0 and output channels % 256 == 0. ------------------------------------------------------- */
+ *      channels % 128 == 0 and output channels % 256 == 0.  amax_y / amax_dx / amax_rowscale: as for the bf16v2 entry points
+ *      (the amax of the result for the NEXT fp8 launch, taken in the epilogue). ------------------------------------ */
 int sg_amax_f32(const float* x, long n, float* amax, void* stream);
 int sg_cvt_fp8(const float* x, void* out, long n, int relu, const float* amax, void* stream);
 int sg_pack_filter_fp8(const float* w, void* out, const float* amax, int taps, int K, int N, int transpose, void* stream);
 int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias, const float* bias2,
-                      float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
+                      float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_y,
+                      void* stream);
 int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, const void* wp8, const float* amax_w, const float* mask,
                            const void* mask16, float* dx, void* dx16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                           int pad_same, int flags, void* stream);
+                           int pad_same, int flags, float* amax_dx, const float* amax_rowscale, void* stream);
 /* fp8 weight gradient (config c5; resnet_ops.py:98,103,109 call sites of the D-shaped trunks, reverse pass of the tapes at
  * data_utils.py:449-468): dw fp32 [kh,kw,Cin,Cout] += sum over pixels of x8 (e4m3, the forward launch's operand copy, ReLU
  * folded in) x dy8 (OCP e5m2 = e5m2(clamp(rowscale * dy * 57344 / amax_dy)), per-sample factors folded in) times

@@ -42,6 +42,8 @@ struct SgIgemm2Args {
   const u16* mask16;   // nullable alternative to `mask`: the same tensor as bf16 (sign and zero are what matter)
   const float* amax_a; // fp8 operands only: device scalars max|activation| and max|filter| behind the per-tensor scales
   const float* amax_w; //   (operand = fp8(value * 448 / amax)); the epilogue multiplies the sums by amax_a * amax_w / 448^2
+  float* amax_out;     // nullable (config c5): amax_out[0] = max(., max |result|), amax_out[1] = max(., max |amax_rowscale[b] * result|)
+  const float* amax_rowscale;   //   -- the per-tensor scales of the NEXT fp8 launch that reads the result, taken while it is written
   int Bn, Ha, Wa, Ca;
   int Hg, Wg, a_sy, a_sx;
   int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   float* stage = reinterpret_cast<float*>(smem + wave * 8192);
   const int c4 = lane & 15, rsub = lane >> 4;
   const int ncol = n0 + wn * 64 + 4 * c4;
+  float amx = 0.f, amx_s = 0.f;          // running max |v| (and max |rowscale v|) of the values this lane stores
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (split == 0) {
     if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + ncol); bsum.x += t.x; bsum.y += t.y; bsum.z += t.z; bsum.w += t.w; }
@@ -674,6 +677,11 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
       }
       if (accum) { v.x += prev[it].x; v.y += prev[it].y; v.z += prev[it].z; v.w += prev[it].w; }
       if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (p.amax_out) {
+        const float a4 = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        amx = fmaxf(amx, a4);
+        if (p.amax_rowscale) amx_s = fmaxf(amx_s, a4 * fabsf(p.amax_rowscale[(m0 + wm * (TM * 32) + i * 32 + 4 * it + rsub) / HW]));
+      }
       *reinterpret_cast<float4*>(p.out + idx[it]) = v;
       if (p.out16) {
         typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -682,6 +690,35 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
         *reinterpret_cast<bf16x4v*>(p.out16 + idx[it]) = h;
       }
     }
+  }
+  if (p.amax_out) {        // (wave-uniform; non-negative floats order like their bit patterns)
+    amx = sg_wave_max(amx);
+    amx_s = p.amax_rowscale ? sg_wave_max(amx_s) : amx;
+    if (lane == 0) {
+      if (amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.amax_out), __float_as_uint(amx));
+      if (amx_s > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.amax_out) + 1, __float_as_uint(amx_s));
+    }
+  }
+}
+
+// amax of the rows a launch summed with float atomics (reduction-split tail tiles: their final values exist only after the
+// kernel): amax2[0] = max(., max |x|), amax2[1] = max(., max |rowscale[row / rows_per_sample] x|); x [rows, N], N % 4 == 0
+__global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, long rows, int N, long row0, const float* __restrict__ rowscale,
+                                                   long rows_per_sample, unsigned* amax_bits) {
+  const int n4 = N >> 2;
+  const long total = rows * n4;
+  float m0 = 0.f, m1 = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[e];
+    const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m0 = fmaxf(m0, a);
+    m1 = fmaxf(m1, rowscale ? a * fabsf(rowscale[(row0 + e / n4) / rows_per_sample]) : a);
+  }
+  m0 = sg_wave_max(m0);
+  m1 = sg_wave_max(m1);
+  if ((threadIdx.x & 63) == 0) {
+    if (m0 > 0.f) atomicMax(amax_bits, __float_as_uint(m0));
+    if (m1 > 0.f) atomicMax(amax_bits + 1, __float_as_uint(m1));
   }
 }
 
@@ -738,6 +775,15 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   }
   hipLaunchKernelGGL((sg_igemm_bf16v2_kernel<BN, ES, RELU>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
+  if (a.amax_out && nsplit > 1) {
+    // the split tiles' values are final only now: their amax comes from a sweep over those rows (identity layouts: the rows
+    // behind row0; otherwise over the whole result -- the full tiles' contribution is then counted twice, harmlessly)
+    const bool ident = (a.flags & SG2_IDENT_OUT) != 0;
+    const long r0 = ident ? row0 : 0, nrows = ident ? M - row0 : (long)a.Bn * a.Ho * a.Wo;
+    const long per_sample = ident ? (long)a.Hg * a.Wg : (long)a.Ho * a.Wo;
+    hipLaunchKernelGGL(k_amax_rows, dim3(sg_grid_for(nrows * (a.N / 4), 256)), dim3(256), 0, s, a.out + (size_t)r0 * a.N, nrows, a.N, r0,
+                       a.amax_rowscale, per_sample, reinterpret_cast<unsigned*>(a.amax_out));
+  }
   return sg_launch_status();
 }
 
@@ -805,12 +851,14 @@ static int finish_twin(const SgIgemm2Args& a, long rows_done, hipStream_t s) {
 }
 
 extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
-                                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+                                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_y,
+                                    void* stream) {
   if (!x16 || !wp_fwd || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
   a.a = (const u16*)x16; a.w = (const u16*)wp_fwd; a.out = y; a.out16 = (u16*)y16; a.bias = bias; a.bias2 = bias2; a.mask = nullptr;
+  a.amax_out = amax_y;
   a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
   a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
   a.ntaps = kh * kw; a.flags = flags;
@@ -822,12 +870,14 @@ extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const f
 }
 
 extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, const float* mask, const void* mask16, float* dx, void* dx16,
-                                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream) {
+                                         int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_dx,
+                                         const float* amax_rowscale, void* stream) {
   if (!dy16 || !wp_bwd || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
   a.a = (const u16*)dy16; a.w = (const u16*)wp_bwd; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask; a.mask16 = (const u16*)mask16;
+  a.amax_out = amax_dx; a.amax_rowscale = amax_rowscale;
   a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
   a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
   a.ntaps = kh * kw; a.flags = flags;
@@ -1391,14 +1441,14 @@ extern "C" int sg_pack_filter_fp8(const float* w, void* out, const float* amax, 
 // SG_ERR_UNSUPPORTED unless reduction channels % 128 == 0 and output channels % 256 == 0 (caller: the bf16 entry points).
 extern "C" int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias,
                                  const float* bias2, float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                                 int pad_same, int flags, void* stream) {
+                                 int pad_same, int flags, float* amax_y, void* stream) {
   if (!x8 || !wp8 || !amax_x || !amax_w || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   if (flags & SG_RELU_IN) return SG_ERR_UNSUPPORTED;           // fold the ReLU into sg_cvt_fp8
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
   a.a = (const u16*)x8; a.w = (const u16*)wp8; a.out = y; a.out16 = (u16*)y16; a.bias = bias; a.bias2 = bias2;
-  a.amax_a = amax_x; a.amax_w = amax_w;
+  a.amax_a = amax_x; a.amax_w = amax_w; a.amax_out = amax_y;
   a.Bn = B; a.Ha = H; a.Wa = W; a.Ca = Cin; a.Hg = Ho; a.Wg = Wo; a.a_sy = 1; a.a_sx = 1;
   a.Ho = Ho; a.Wo = Wo; a.N = Cout; a.o_sy = 1; a.o_sx = 1; a.o_oy = 0; a.o_ox = 0;
   a.ntaps = kh * kw; a.flags = flags;
@@ -1411,13 +1461,13 @@ extern "C" int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void
 
 extern "C" int sg_conv2d_bwd_data_fp8(const void* dy8, const float* amax_dy, const void* wp8, const float* amax_w, const float* mask,
                                       const void* mask16, float* dx, void* dx16, int B, int H, int W, int Cin, int Cout, int kh,
-                                      int kw, int pad_same, int flags, void* stream) {
+                                      int kw, int pad_same, int flags, float* amax_dx, const float* amax_rowscale, void* stream) {
   if (!dy8 || !wp8 || !amax_dy || !amax_w || !dx || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
   a.a = (const u16*)dy8; a.w = (const u16*)wp8; a.out = dx; a.out16 = (u16*)dx16; a.mask = mask; a.mask16 = (const u16*)mask16;
-  a.amax_a = amax_dy; a.amax_w = amax_w;
+  a.amax_a = amax_dy; a.amax_w = amax_w; a.amax_out = amax_dx; a.amax_rowscale = amax_rowscale;
   a.Bn = B; a.Ha = Ho; a.Wa = Wo; a.Ca = Cout; a.Hg = H; a.Wg = W; a.a_sy = 1; a.a_sx = 1;
   a.Ho = H; a.Wo = W; a.N = Cin; a.o_sy = 1; a.o_sx = 1;
   a.ntaps = kh * kw; a.flags = flags;

@@ -249,7 +249,8 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
                 ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     # (bf16 twin of d_c1 from the epilogue, unless both of its consumers -- conv1's weight-grad and data-grad -- read fp8 copies)
     cin, cout = x.shape[-1], c1.shape[-1]
-    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True))
+    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True),
+                               amax_scale=wscale)
     if want_dw:
         with ops.side_stream(x, d_c1, wscale):
             ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
@@ -259,7 +260,7 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
         dx = ops.avgpool2_bwd(ops.conv2d_bwd_data(dout, p[pre + ".short.w"], (H // 2, W // 2)))
     else:
         dx = ops.conv2d_bwd_data(d_c2, p[pre + ".short.w"], (H, W))
-    ops.conv2d_bwd_data(d_c1, p[pre + ".conv1.w"], (H, W), mask=x, out=dx, accum=True)
+    ops.conv2d_bwd_data(d_c1, p[pre + ".conv1.w"], (H, W), mask=x, out=dx, accum=True, amax_scale=wscale)    # (dx = the block below's dout)
     return dx
 
 

@@ -245,10 +245,12 @@ def fp8_of(t: torch.Tensor, relu: bool = False):
     e = _TWINS.get(key)
     if e is None:
         _chk(t)
-        amax = torch.zeros(1, device=t.device)
+        rec = _amax_get(t)                       # the producing conv's epilogue already took max |t|
+        amax = rec[0:1] if rec is not None else torch.zeros(1, device=t.device)
         out = torch.empty(t.shape, device=t.device, dtype=torch.uint8)
-        with _hbm("cvt_fp8", t, t, out):
-            call("sg_amax_f32", _p(t), t.numel(), _p(amax), _stream())
+        with _hbm("cvt_fp8", t if rec is None else None, t, out):
+            if rec is None:
+                call("sg_amax_f32", _p(t), t.numel(), _p(amax), _stream())
             call("sg_cvt_fp8", _p(t), out.data_ptr(), t.numel(), int(relu), _p(amax), _stream())
         e = (t, out, amax)
         _TWINS[key] = e
@@ -274,13 +276,15 @@ def grad_operand_fp8(dy: torch.Tensor, sample_scale, want_colsum: bool):
         M = dy.numel() // C
         k4 = (dy.untyped_storage().data_ptr(), "fp8", False, dy.storage_offset(), dy.numel())
         have4 = k4 in _TWINS
-        amax2 = torch.zeros(2, device=dy.device)
+        rec = _amax_get(dy, sample_scale, need_scaled=True)
+        amax2 = rec if rec is not None else torch.zeros(2, device=dy.device)
         out5 = torch.empty(dy.shape, device=dy.device, dtype=torch.uint8)
         out4 = None if have4 else torch.empty(dy.shape, device=dy.device, dtype=torch.uint8)
         colsum = torch.zeros(C, device=dy.device, dtype=torch.float32)
         rows = (M // sample_scale.numel()) if sample_scale is not None else 1
-        with _hbm("cvt_fp8", dy, dy, out5, out4):
-            call("sg_amax2_f32", _p(dy), dy.numel(), _p(sample_scale), rows * C, _p(amax2), _stream())
+        with _hbm("cvt_fp8", dy if rec is None else None, dy, out5, out4):
+            if rec is None:
+                call("sg_amax2_f32", _p(dy), dy.numel(), _p(sample_scale), rows * C, _p(amax2), _stream())
             call("sg_cvt_fp8_grad", _p(dy), out5.data_ptr(), None if out4 is None else out4.data_ptr(), M, C, _p(sample_scale), rows,
                  _p(amax2), _p(colsum), _stream())
         if out4 is not None:
@@ -296,6 +300,9 @@ def _amax2_of(dy: torch.Tensor, sample_scale) -> torch.Tensor:
     e = _TWINS.get((dy.untyped_storage().data_ptr(), "g8", sptr, dy.storage_offset(), dy.numel()))
     if e is not None:
         return e[5]
+    rec = _amax_get(dy, sample_scale, need_scaled=True)
+    if rec is not None:
+        return rec
     key = (dy.untyped_storage().data_ptr(), "a2", sptr, dy.storage_offset(), dy.numel())
     e = _TWINS.get(key)
     if e is None:
@@ -447,8 +454,43 @@ USE_V2 = _os.environ.get("SG_BF16_V2", "1") == "1"
 _TWINS = {}
 
 
+_AMAX_POOL = {"buf": None, "next": 0}
+
+
+def _amax_slot(like: torch.Tensor) -> torch.Tensor:
+    """Two zeroed floats (max |t|, max |scale t|) from a per-step pool: ONE memset launch per 1024 convolutions."""
+    pool = _AMAX_POOL
+    if pool["buf"] is None or pool["next"] + 2 > pool["buf"].numel() or pool["buf"].device != like.device:
+        pool["buf"] = torch.zeros(2048, device=like.device)
+        pool["next"] = 0
+    s = pool["buf"][pool["next"]:pool["next"] + 2]
+    pool["next"] += 2
+    return s
+
+
+def _want_amax() -> bool:
+    """config c5: conv epilogues record the amax of their result for the fp8 launch that reads it next."""
+    return CONV_DTYPE == "fp8" and not _FP8_BLOCK[0]
+
+
+def _amax_put(t: torch.Tensor, slot: torch.Tensor, scale) -> None:
+    if t.storage_offset() == 0 and t.numel() * 4 == t.untyped_storage().nbytes():
+        _TWINS[(t.untyped_storage().data_ptr(), "amax")] = (t, slot, 0 if scale is None else scale.data_ptr())
+
+
+def _amax_get(t: torch.Tensor, scale=None, need_scaled: bool = False):
+    """The producer-recorded amax pair of a WHOLE tensor, or None.  need_scaled: element 1 must belong to `scale`."""
+    e = _TWINS.get((t.untyped_storage().data_ptr(), "amax"))
+    if e is None or t.storage_offset() != 0 or t.numel() != e[0].numel():
+        return None
+    if need_scaled and e[2] != (0 if scale is None else scale.data_ptr()):
+        return None
+    return e[1]
+
+
 def new_step() -> None:
     _TWINS.clear()
+    _AMAX_POOL["buf"] = None
 
 
 def _touch(t) -> None:
@@ -583,15 +625,20 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
             x8, ax = fp8_of(x, relu_in)                       # the operand ReLU is folded into the conversion
             w8, aw = packed_filter_fp8(w, "fwd")
             y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            am = _amax_slot(out)
             call("sg_conv2d_fwd_fp8", x8.data_ptr(), _p(ax), w8.data_ptr(), _p(aw), _p(bias), _p(bias2), _p(out),
-                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(False, accum, relu_out), _stream())
+                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(False, accum, relu_out), _p(am), _stream())
+            _amax_put(out, am, None)
             if y16 is not None:
                 _twin_put(out, y16)
         elif _v2_ok(Cin, Cout, kh, kw, same) and not tanh_out:
             x16 = bf16_of(x)
             y16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
+            am = _amax_slot(out) if _want_amax() else None
             call("sg_conv2d_fwd_bf16v2", x16.data_ptr(), packed_filter(w, "fwd").data_ptr(), _p(bias), _p(bias2), _p(out),
-                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in, accum, relu_out), _stream())
+                 None if y16 is None else y16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(relu_in, accum, relu_out), _p(am), _stream())
+            if am is not None:
+                _amax_put(out, am, None)
             if y16 is not None:
                 _twin_put(out, y16)
         elif _f32v2_ok(Cin, Cout, kh, kw, same, out.shape[0] * out.shape[1] * out.shape[2]) and not tanh_out:
@@ -606,8 +653,10 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
     return out
 
 
-def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=None, accum=False, want16=False):
-    _chk(dy, w, mask, out)
+def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=None, accum=False, want16=False, amax_scale=None):
+    """amax_scale [B] (optional, config c5): the per-sample factors the result will carry as a weight-grad operand -- the epilogue
+    records max |dx| and max |amax_scale[b] dx| for the fp8 conversion of dx (no amax sweep)."""
+    _chk(dy, w, mask, out, amax_scale)
     B = dy.shape[0]
     H, W = in_hw
     kh, kw, Cin, Cout = w.shape
@@ -623,18 +672,24 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
             w8, aw = packed_filter_fp8(w, "bwd")
             dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
             m16 = None if mask is None else _twin_get(mask)
+            am = _amax_slot(out)
             call("sg_conv2d_bwd_data_fp8", dy8.data_ptr(), _p(ady), w8.data_ptr(), _p(aw), None if m16 is not None else _p(mask),
                  None if m16 is None else m16.data_ptr(), _p(out), None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout,
-                 kh, kw, int(same), _flags(accum=accum), _stream())
+                 kh, kw, int(same), _flags(accum=accum), _p(am), _p(amax_scale), _stream())
+            _amax_put(out, am, amax_scale)
             if dx16 is not None:
                 _twin_put(out, dx16)
         elif _v2_ok(Cout, Cin, kh, kw, same):
             dy16 = bf16_of(dy)
             dx16 = torch.empty(out.shape, device=out.device, dtype=torch.bfloat16) if want16 else None
             m16 = None if mask is None else _twin_get(mask)          # the ReLU mask as bf16 when a twin exists (half the bytes)
+            am = _amax_slot(out) if _want_amax() else None
             call("sg_conv2d_bwd_data_bf16v2", dy16.data_ptr(), packed_filter(w, "bwd").data_ptr(), None if m16 is not None else _p(mask),
                  None if m16 is None else m16.data_ptr(), _p(out),
-                 None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _stream())
+                 None if dx16 is None else dx16.data_ptr(), B, H, W, Cin, Cout, kh, kw, int(same), _flags(accum=accum), _p(am),
+                 _p(amax_scale), _stream())
+            if am is not None:
+                _amax_put(out, am, amax_scale)
             if dx16 is not None:
                 _twin_put(out, dx16)
         elif _f32v2_ok(Cout, Cin, kh, kw, same, B * H * W):

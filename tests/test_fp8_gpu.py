@@ -207,3 +207,37 @@ def test_train_step_fp8_tracks_fp32(dev, fp8_mode):
         a, b = g32_[n].double(), g8[n].double()
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > (0.8 if n == "G" else 0.9), "%s: cosine %.4f" % (n, cos)
+
+
+@pytest.mark.parametrize("B", [2, 40])       # 2: every tile is a reduction-split tail tile (amax from the tail sweep); 40: full rounds + tail
+def test_fp8_producer_amax_is_the_amax_of_the_result(dev, gen, fp8_mode, B):
+    """Config c5: the conv epilogue records max |result| (and max |scale_b result| for a gradient) while it writes the result, so
+    the fp8 conversion of that result needs no amax sweep.  The recorded pair must be BITWISE the amax of the tensor the kernel
+    wrote (forward with bias, data-grad with ReLU mask / accumulate / per-sample factors), and ops.fp8_of / grad_operand_fp8 must
+    produce the same bytes with it as with the sweep."""
+    ops = fp8_mode
+    H, W, C = 8, 40, 512
+    x = g32(rnd(gen, B, H, W, C), dev)
+    w = g32(rnd(gen, 3, 3, C, C) / math.sqrt(9 * C), dev)
+    b = g32(rnd(gen, C), dev)
+    sc = g32(torch.rand(B, generator=gen, dtype=torch.float64) * 2 - 0.5, dev)
+    y = ops.conv2d_fwd(x, w, b, relu_in=True)
+    rec = ops._amax_get(y)
+    assert rec is not None and rec[0].item() == y.abs().max().item() and rec[1].item() == rec[0].item()
+    got, a = ops.fp8_of(y, relu=True)
+    ops.new_step()                                   # forget the recorded amax: the sweep path
+    ref, a_ref = ops.fp8_of(y, relu=True)
+    assert a.item() == a_ref.item() and torch.equal(got, ref)
+    dy = g32(rnd(gen, B, H, W, C), dev)
+    base = g32(rnd(gen, B, H, W, C), dev)
+    dx = ops.conv2d_bwd_data(dy, w, (H, W), mask=x, out=base.clone(), accum=True, amax_scale=sc)
+    rec = ops._amax_get(dx, sc, need_scaled=True)
+    assert rec is not None and rec[0].item() == dx.abs().max().item()
+    assert rec[1].item() == (dx.abs() * sc.abs().view(B, 1, 1, 1)).max().item()
+    assert ops._amax_get(dx, None, need_scaled=True) is None            # recorded for other factors: not usable unscaled
+    o5, a5, cs = ops.grad_operand_fp8(dx, sc, True)
+    o4, a4 = ops.fp8_of(dx)
+    ops.new_step()
+    o5r, a5r, csr = ops.grad_operand_fp8(dx, sc, True)
+    o4r, a4r = ops.fp8_of(dx)
+    assert a5.item() == a5r.item() and a4.item() == a4r.item() and torch.equal(o5, o5r) and torch.equal(o4, o4r)

@@ -805,7 +805,6 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
   w_elems += (long)a.N * a.Ca;
   if (a_bytes >= (1L << 32) - 64 || es * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
-  if (es == 1) return sg2_launch_bn<256, 1>(a, s, twin_rows_done);
   // Tile width: the widest one that divides N, unless the launch cannot be cut along the reduction (a fused output ReLU
   // rules the float-atomic tail split out) and a narrower tile fills the 256 CUs' rounds better.  Relative tile times:
   // the bf16 loop is bound by the L2 -> LDS feed ((256 + BN) x 128 bytes per tile), the fp32 loop by the matrix pipe.
@@ -817,11 +816,18 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
     if (a.N % c) continue;
     const long tiles = m_tiles * (a.N / c);
     const double rounds = can_split && tiles % 256 ? (tiles < 256 ? 1.0 : (double)tiles / 256.0) : (double)((tiles + 255) / 256);
-    const double t_tile = es == 4 ? (c == 256 ? 1.0 : c == 128 ? 0.525 : 0.29) : (c == 256 ? 1.0 : c == 128 ? 0.75 : 0.625);
+    // (fp8: the loop moves the same bytes per tile as bf16 in half the matrix time -- the narrow tiles lose more)
+    const double t_tile = es == 4 ? (c == 256 ? 1.0 : c == 128 ? 0.525 : 0.29) : es == 1 ? (c == 256 ? 1.0 : c == 128 ? 0.8 : 0.7)
+                                                                                        : (c == 256 ? 1.0 : c == 128 ? 0.75 : 0.625);
     if (rounds * t_tile < 0.97 * best) { best = rounds * t_tile; bn = c; }
   }
   static const int bn_env = getenv("SG2_FORCE_BN") ? atoi(getenv("SG2_FORCE_BN")) : 0;      // (debugging aid)
   if (bn_env > 0 && a.N % bn_env == 0) bn = bn_env;
+  if (es == 1) {          // (narrow tiles: the small grids of the 8-way shard batch -- 160 tiles of 256 x 256 on the 4x20 layers at B = 128)
+    if (bn == 256) return sg2_launch_bn<256, 1>(a, s, twin_rows_done);
+    if (bn == 128) return sg2_launch_bn<128, 1>(a, s, twin_rows_done);
+    return sg2_launch_bn<64, 1>(a, s, twin_rows_done);
+  }
   if (es == 4) {
     if (bn == 256) return sg2_launch_bn<256, 4>(a, s, twin_rows_done);
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);

@@ -17,8 +17,12 @@
 #define SG_TANH_OUT 8   // apply tanh to the result (thin Cout=1 path only)
 #define SG_MMA_BF16 256 // weight-grad: round the matrix-core operands to bf16 (fp32 accumulation); config c3
 
+#include <stdio.h>
 static inline int sg_launch_status() {
-  return hipGetLastError() == hipSuccess ? SG_OK : SG_ERR_LAUNCH;
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return SG_OK;
+  fprintf(stderr, "[libscrabble_hip] kernel launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));   // (the C-ABI returns a code only)
+  return SG_ERR_LAUNCH;
 }
 
 // sg_set_deterministic (conv_igemm.hip): when on, no convolution launch lets two workgroups add into the same output address

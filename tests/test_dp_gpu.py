@@ -113,8 +113,9 @@ def test_two_rank_step_equals_single_process(dev, balance, tmp_path):
         err, scale, werr = stats[n]
         # deterministic mode on both sides: what is left is the association of the two ranks' partial sums (a + b summed by the
         # all-reduce instead of one chain over the batch), BatchNorm's float-atomic per-sample partials and fp64 -> fp32 of
-        # the SyncBN statistics: 2e-4 of the largest gradient (1e-3 before the weight-grads had a fixed order)
-        assert err <= 2e-4 * scale, "%s gradients: max err %.3e vs scale %.3e" % (n, err, scale)
+        # the SyncBN statistics: 2e-5 of the largest gradient (measured on MI355X: 4e-7 D / S, 8e-8 R, 3.6e-6 G,
+        # profiles/r03_dp_two_rank_vs_single.txt; the bar was 1e-3 before the weight-grads had a fixed order)
+        assert err <= 2e-5 * scale, "%s gradients: max err %.3e vs scale %.3e" % (n, err, scale)
         assert werr <= 4.1e-4, n
 
 

@@ -7,13 +7,15 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/${1:-gpurun_out/prof}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-kernel-timing"
+B="$R/bench.py --no-cpu-baseline --no-kernel-timing --no-extra-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats128 -o run -- python3 $B --steps 2 --warmup 1 > $O/stats128.log 2>&1
 echo stats128 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats16 -o run -- python3 $B --steps 4 --warmup 2 --batch 16 > $O/stats16.log 2>&1
 echo stats16 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o run -- python3 $B --steps 2 --warmup 1 --conv-dtype bf16 --batch 256 > $O/stats_bf16.log 2>&1
 echo stats_bf16 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp8 -o run -- python3 $B --steps 2 --warmup 1 --conv-dtype fp8 --batch 512 --balance > $O/stats_fp8.log 2>&1
+echo stats_fp8 done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_fetch.log 2>&1
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_write.log 2>&1
@@ -33,6 +35,15 @@ python3 $R/tools/pmc_traffic.py $O/pmc_fetch16/run_counter_collection.csv $O/pmc
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch16/run_counter_collection.csv $O/pmc_write16/run_counter_collection.csv --kernel sg_wgrad_bf16v2_kernel \
   --command "$CMD --conv-dtype bf16 --batch 256" --out $O/wgrad_bf16_traffic_bs256.json >> $O/traffic.log 2>&1
 rm -f $O/pmc_fetch16/run_counter_collection.csv $O/pmc_write16/run_counter_collection.csv $O/*/run_kernel_trace.csv.bak
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch8 -o run -- python3 $B --steps 1 --warmup 1 --conv-dtype fp8 --batch 512 --balance > $O/pmc_fetch8.log 2>&1
+echo fetch fp8 done
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write8 -o run -- python3 $B --steps 1 --warmup 1 --conv-dtype fp8 --batch 512 --balance > $O/pmc_write8.log 2>&1
+echo write fp8 done
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch8/run_counter_collection.csv $O/pmc_write8/run_counter_collection.csv --kernel "sg_igemm_bf16v2_kernel<256, 1" \
+  --command "$CMD --conv-dtype fp8 --batch 512 --balance" --out $O/igemm_fp8_traffic_bs512.json >> $O/traffic.log 2>&1
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch8/run_counter_collection.csv $O/pmc_write8/run_counter_collection.csv --kernel sg_wgrad_fp8_kernel \
+  --command "$CMD --conv-dtype fp8 --batch 512 --balance" --out $O/wgrad_fp8_traffic_bs512.json >> $O/traffic.log 2>&1
+rm -f $O/pmc_fetch8/run_counter_collection.csv $O/pmc_write8/run_counter_collection.csv
 # clock and matrix-pipe occupancy of the conv kernels on one layer (GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES), the bare
 # MFMA rates of this device and the constant / per-k-tile split of the DMA-fed kernels
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/clk -o run -- python3 $R/tools/probe_clock.py run > $O/clk.log 2>&1

@@ -695,8 +695,8 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     amx = sg_wave_max(amx);
     amx_s = p.amax_rowscale ? sg_wave_max(amx_s) : amx;
     if (lane == 0) {
-      if (amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.amax_out), __float_as_uint(amx));
-      if (amx_s > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.amax_out) + 1, __float_as_uint(amx_s));
+      sg_atomic_max_nonneg(p.amax_out, amx);
+      sg_atomic_max_nonneg(p.amax_out + 1, amx_s);
     }
   }
 }
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, 
   m0 = sg_wave_max(m0);
   m1 = sg_wave_max(m1);
   if ((threadIdx.x & 63) == 0) {
-    if (m0 > 0.f) atomicMax(amax_bits, __float_as_uint(m0));
-    if (m1 > 0.f) atomicMax(amax_bits + 1, __float_as_uint(m1));
+    sg_atomic_max_nonneg(reinterpret_cast<float*>(amax_bits), m0);
+    sg_atomic_max_nonneg(reinterpret_cast<float*>(amax_bits) + 1, m1);
   }
 }
 
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long 
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
   m = sg_wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));      // non-negative floats order like their bits
+  if ((threadIdx.x & 63) == 0) sg_atomic_max_nonneg(reinterpret_cast<float*>(amax_bits), m);
 }
 
 // amax[0] = max(amax[0], max_i |x_i|); the caller zeroes amax first.  n % 4 == 0.

@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256) void k_amax2(const float* __restrict__ x, long
   m0 = sg_wave_max(m0);
   m1 = sg_wave_max(m1);
   if ((threadIdx.x & 63) == 0) {
-    if (m0 > 0.f) atomicMax(amax_bits, __float_as_uint(m0));          // non-negative floats order like their bits
-    if (m1 > 0.f) atomicMax(amax_bits + 1, __float_as_uint(m1));
+    sg_atomic_max_nonneg(reinterpret_cast<float*>(amax_bits), m0);
+    sg_atomic_max_nonneg(reinterpret_cast<float*>(amax_bits) + 1, m1);
   }
 }
 

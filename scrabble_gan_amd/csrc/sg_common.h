@@ -52,6 +52,18 @@ __device__ __forceinline__ float sg_wave_max(float v) {
   return v;
 }
 
+// amax[0] = max(amax[0], m) for a non-negative float m (non-negative floats order like their bit patterns).  The value only
+// grows, so a wave first LOOKS (agent-scope load: no stale L1 line) and adds only when it would raise it: a launch's tens
+// of thousands of waves otherwise queue on ONE address (30 720 workgroups x 8 waves cost the 64-filter layers 20 ms per
+// step in fp8 mode before this check -- same-address atomics serialise at ~70 ns each).
+__device__ __forceinline__ void sg_atomic_max_nonneg(float* amax, float m) {
+  if (m <= 0.f) return;
+  unsigned* p = reinterpret_cast<unsigned*>(amax);
+  const unsigned bits = __float_as_uint(m);
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= bits) return;
+  atomicMax(p, bits);
+}
+
 __device__ __forceinline__ double sg_wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

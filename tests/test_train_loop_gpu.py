@@ -194,16 +194,25 @@ def test_full_state_save_and_resume(dev, tmp_path):
             DU.train_step(0, i, 9, images, labels, D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_imgs, B, 128, net_loss.hinge, 1, 0,
                           words, 10, "", verbose=False)
 
-    a = build()
-    steps(a, 0, 3)
-    b = build()
-    steps(b, 0, 2)
-    path = str(tmp_path / "state" / "latest.safetensors")
-    DU.save_training_state(path, b[0], b[1], b[2], b[3], *b[5], epoch_idx=0, batch_idx=2)
-    c = build()                                               # fresh weights, fresh optimizers
-    assert DU.load_training_state(path, c[0], c[1], c[2], c[3], *c[5]) == (0, 2)
-    assert all(o.iterations == 2 for o in c[5])
-    steps(c, 2, 1)
+    # Both runs in the deterministic mode (configure(deterministic=True)): every conv output and every dW / db element has
+    # one adder, so what still differs between two runs of the same step is the float-atomic remainder listed in
+    # ops.set_deterministic (BatchNorm's per-sample partials, the filter bank's dz, the attention key sweep at this tiny batch).
+    from scrabble_gan_amd import ops
+    ops.set_deterministic(True)
+    try:
+        a = build()
+        steps(a, 0, 3)
+        b = build()
+        steps(b, 0, 2)
+        path = str(tmp_path / "state" / "latest.safetensors")
+        DU.save_training_state(path, b[0], b[1], b[2], b[3], *b[5], epoch_idx=0, batch_idx=2)
+        c = build()                                               # fresh weights, fresh optimizers
+        assert DU.load_training_state(path, c[0], c[1], c[2], c[3], *c[5]) == (0, 2)
+        assert all(o.iterations == 2 for o in c[5])
+        steps(c, 2, 1)
+    finally:
+        ops.set_deterministic(False)
+    lines = []
     for ma, mc, oa, oc in zip(a[:4], c[:4], a[5], c[5]):
         assert oa.iterations == oc.iterations == 3
         # Float-atomic summation order moves gradients in their last bits; Adam (beta_1 = 0) normalises every component to
@@ -215,9 +224,15 @@ def test_full_state_save_and_resume(dev, tmp_path):
         assert (ma.store.state - mc.store.state).abs().max().item() <= 1e-5, ma.name
         for k in ("m", "v"):
             sa, sc = oa.flat_state(ma.store)[k], oc.flat_state(mc.store)[k]
-            # (the last gradient and its running square: run-to-run noise of the float atomics, amplified where a ReLU /
-            #  max-pool decision sits on the edge -- the same 1e-3-of-max bar as the data-parallel comparison)
-            assert (sa - sc).abs().max().item() <= 5e-3 * sa.abs().max().item() + 1e-12, (ma.name, k, (sa - sc).abs().max().item(), sa.abs().max().item())
+            # (the last gradient and its running square; deterministic mode leaves the float-atomic remainder, amplified
+            #  where a ReLU / max-pool decision sits on the edge: 1e-3 of the slot's largest entry, 5e-3 before dW had a fixed order)
+            lines.append("%s %s: max |resumed - continuous| %.3e of %.3e" % (ma.name, k, (sa - sc).abs().max().item(), sa.abs().max().item()))
+            assert (sa - sc).abs().max().item() <= 1e-3 * sa.abs().max().item() + 1e-12, (ma.name, k, (sa - sc).abs().max().item(), sa.abs().max().item())
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        open("gpurun_out/resume_vs_continuous.txt", "w").write("\n".join(lines) + "\n")
+    except OSError:
+        pass
 
 
 def test_device_prefetcher_matches_the_host_loader(dev, tmp_path):

@@ -325,10 +325,10 @@ extern "C" int sg_attention_fwd(const float* theta, const float* phi, const floa
   if (B < 1 || Nq < 1) return SG_OK;
   const int cfg = at_q_cfg(Nq, B);
   hipStream_t s = (hipStream_t)stream;
-  if (cfg == 256) hipLaunchKernelGGL((k_attn_fwd<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
-  else if (cfg == 128) hipLaunchKernelGGL((k_attn_fwd<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
-  else if (cfg == 64) hipLaunchKernelGGL((k_attn_fwd<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, Nq, Nk);
-  else hipLaunchKernelGGL((k_attn_fwd<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  if (cfg == 256) SG_KERNEL((k_attn_fwd<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else if (cfg == 128) SG_KERNEL((k_attn_fwd<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else if (cfg == 64) SG_KERNEL((k_attn_fwd<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, Nq, Nk);
+  else SG_KERNEL((k_attn_fwd<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, Nq, Nk);
   return sg_launch_status();
 }
 
@@ -342,13 +342,13 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   hipStream_t s = (hipStream_t)stream;
   const int cfg = at_q_cfg(Nq, B);
   if (cfg == 256)
-    hipLaunchKernelGGL((k_attn_bwd_dq<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+    SG_KERNEL((k_attn_bwd_dq<4, 2>), dim3(sg_cdiv(Nq, 256), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else if (cfg == 128)
-    hipLaunchKernelGGL((k_attn_bwd_dq<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+    SG_KERNEL((k_attn_bwd_dq<4, 1>), dim3(sg_cdiv(Nq, 128), B), dim3(256), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else if (cfg == 64)
-    hipLaunchKernelGGL((k_attn_bwd_dq<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+    SG_KERNEL((k_attn_bwd_dq<2, 1>), dim3(sg_cdiv(Nq, 64), B), dim3(128), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   else
-    hipLaunchKernelGGL((k_attn_bwd_dq<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
+    SG_KERNEL((k_attn_bwd_dq<1, 1>), dim3(sg_cdiv(Nq, 32), B), dim3(64), 0, s, theta, phi, g, out, lse, dout, dtheta, delta, Nq, Nk);
   // key sweep: every workgroup stages ALL queries of its z slice, so the more keys it owns the better that is amortised:
   // the widest of 128 / 64 / 32 keys per workgroup that still gives two rounds of workgroups and wastes the fewest padded
   // key lanes; then split the query range until the grid fills the chip
@@ -374,8 +374,8 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
       return SG_ERR_LAUNCH;
   }
   const dim3 grid(sg_cdiv(Nk, 32 * kw), B, zs);
-  if (kw == 4) hipLaunchKernelGGL((k_attn_bwd_dkv<4>), grid, dim3(256), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
-  else if (kw == 2) hipLaunchKernelGGL((k_attn_bwd_dkv<2>), grid, dim3(128), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
-  else hipLaunchKernelGGL((k_attn_bwd_dkv<1>), grid, dim3(64), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
+  if (kw == 4) SG_KERNEL((k_attn_bwd_dkv<4>), grid, dim3(256), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
+  else if (kw == 2) SG_KERNEL((k_attn_bwd_dkv<2>), grid, dim3(128), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
+  else SG_KERNEL((k_attn_bwd_dkv<1>), grid, dim3(64), 0, s, theta, phi, g, lse, dout, delta, dphi, dg, Nq, Nk, q_chunk);
   return sg_launch_status();
 }

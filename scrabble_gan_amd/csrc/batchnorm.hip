@@ -213,21 +213,21 @@ extern "C" long sg_bn_stats_workspace_floats(long M, int C) { return (long)sg_cd
 extern "C" int sg_bn_stats_sums(const float* x, long M, int C, float* workspace, double* sums, void* stream) {
   if (!x || !workspace || !sums || !chan_ok(C)) return SG_ERR_ARG;
   const int rpb = bn_stats_rpb(M), nblk = sg_cdiv(M, rpb);
-  hipLaunchKernelGGL(k_bn_stats_partial, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, workspace, M, C, rpb);
-  hipLaunchKernelGGL(k_bn_stats_combine, dim3(sg_cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, workspace, sums, nblk, C);
+  SG_KERNEL(k_bn_stats_partial, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, workspace, M, C, rpb);
+  SG_KERNEL(k_bn_stats_combine, dim3(sg_cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, workspace, sums, nblk, C);
   return sg_launch_status();
 }
 
 extern "C" int sg_bn_stats_finalize(const double* sums, double count, float* mean, float* var, int C, void* stream) {
   if (!sums || !mean || !var || count <= 0) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, mean, var, C);
+  SG_KERNEL(k_bn_stats_finalize, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, mean, var, C);
   return sg_launch_status();
 }
 
 extern "C" int sg_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                            int gstride, float* y, int B, int HW, int C, float eps, int relu, void* stream) {
   if (!x || !mean || !var || !gamma || !beta || !y || (C & 3)) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_apply, dim3(sg_grid_for((long)B * HW * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, mean, var,
+  SG_KERNEL(k_bn_apply, dim3(sg_grid_for((long)B * HW * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, mean, var,
                      gamma, beta, gstride, y, B, HW, C, eps, relu);
   return sg_launch_status();
 }
@@ -239,9 +239,9 @@ extern "C" int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x,
   if (!dy || !x || !mean || !var || !gamma || !dgamma || !dbeta || !chan || !chan_ok(C) || (relu && !y)) return SG_ERR_ARG;
   long r = ((long)HW * B + 511) / 512;                  // ~512 workgroups; <= HW / 16 float atomics per [b, c] address
   const int rpb = (int)(r < 16 ? 16 : (r > 512 ? 512 : r));
-  hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(sg_cdiv(HW, rpb), B), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, var, dgamma,
+  SG_KERNEL(k_bn_bwd_reduce, dim3(sg_cdiv(HW, rpb), B), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, var, dgamma,
                      dbeta, HW, C, eps, relu, rpb);
-  hipLaunchKernelGGL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan,
+  SG_KERNEL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan,
                      dgamma_c, dbeta_c);
   return sg_launch_status();
 }
@@ -250,7 +250,7 @@ extern "C" int sg_bn_bwd_apply(const float* dy, const float* y, const float* x, 
                                const float* gamma, int gstride, const double* chan, double count, float* dx, int B, int HW,
                                int C, float eps, int relu, int use_stats, void* stream) {
   if (!dy || !x || !mean || !var || !gamma || !dx || (C & 3) || (relu && !y) || (use_stats && (!chan || count <= 0))) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(sg_grid_for((long)B * HW * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, y, x,
+  SG_KERNEL(k_bn_bwd_apply, dim3(sg_grid_for((long)B * HW * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, y, x,
                      mean, var, gamma, gstride, chan, count, dx, B, HW, C, eps, relu, use_stats);
   return sg_launch_status();
 }
@@ -258,6 +258,6 @@ extern "C" int sg_bn_bwd_apply(const float* dy, const float* y, const float* x, 
 extern "C" int sg_bn_update_moving(float* mm, float* mv, const float* mean, const float* var, double count, float momentum,
                                    int C, void* stream) {
   if (!mm || !mv || !mean || !var) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_update_moving, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mm, mv, mean, var, count, momentum, C);
+  SG_KERNEL(k_bn_update_moving, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mm, mv, mean, var, count, momentum, C);
   return sg_launch_status();
 }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_cvt_bf16(const float* __restrict__ x, u
 extern "C" int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream) {
   if (!x || !out || n < 0 || (n & 7) || (rowscale && (rowlen <= 0 || (rowlen & 7)))) return SG_ERR_ARG;
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, n / 8, relu, rowscale, rowlen);
+  SG_KERNEL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, n / 8, relu, rowscale, rowlen);
   return sg_launch_status();
 }
 
@@ -160,7 +160,7 @@ extern "C" int sg_cvt_bf16_bias(const float* x, void* out, void* out_plain, long
   long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
   if (sg_deterministic()) r = M;              // one workgroup, one adder per column (slow: a reproducibility mode)
   const int rpb = (int)(r < 32 ? 32 : r);
-  hipLaunchKernelGGL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, (u16*)out_plain, M, C,
+  SG_KERNEL(k_cvt_bf16_bias, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, (u16*)out_plain, M, C,
                      rowscale, rows_per_sample, dbias, rpb);
   return sg_launch_status();
 }
@@ -773,7 +773,7 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_igemm_bf16v2_kernel<BN, ES, RELU>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  SG_KERNEL((sg_igemm_bf16v2_kernel<BN, ES, RELU>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   if (a.amax_out && nsplit > 1) {
     // the split tiles' values are final only now: their amax comes from a sweep over those rows (identity layouts: the rows
@@ -781,7 +781,7 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
     const bool ident = (a.flags & SG2_IDENT_OUT) != 0;
     const long r0 = ident ? row0 : 0, nrows = ident ? M - row0 : (long)a.Bn * a.Ho * a.Wo;
     const long per_sample = ident ? (long)a.Hg * a.Wg : (long)a.Ho * a.Wo;
-    hipLaunchKernelGGL(k_amax_rows, dim3(sg_grid_for(nrows * (a.N / 4), 256)), dim3(256), 0, s, a.out + (size_t)r0 * a.N, nrows, a.N, r0,
+    SG_KERNEL(k_amax_rows, dim3(sg_grid_for(nrows * (a.N / 4), 256)), dim3(256), 0, s, a.out + (size_t)r0 * a.N, nrows, a.N, r0,
                        a.amax_rowscale, per_sample, reinterpret_cast<unsigned*>(a.amax_out));
   }
   return sg_launch_status();
@@ -851,7 +851,7 @@ static int finish_twin(const SgIgemm2Args& a, long rows_done, hipStream_t s) {
   const long M = (long)a.Bn * a.Ho * a.Wo;
   if (rows_done >= M) return SG_OK;
   const long n = (M - rows_done) * a.N;
-  hipLaunchKernelGGL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, s, a.out + (size_t)rows_done * a.N,
+  SG_KERNEL(k_cvt_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, s, a.out + (size_t)rows_done * a.N,
                      a.out16 + (size_t)rows_done * a.N, n / 8, 0, (const float*)nullptr, 8L);
   return sg_launch_status();
 }
@@ -1301,7 +1301,7 @@ static int sg2_launch_wgrad(SgWgrad2Args a, long M, hipStream_t s) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_wgrad_bf16v2_kernel<CT, NT, STRIDED>), dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, s, a);
+  SG_KERNEL((sg_wgrad_bf16v2_kernel<CT, NT, STRIDED>), dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, s, a);
   return sg_launch_status();
 }
 
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256) void k_amax(const float* __restrict__ x, long 
 extern "C" int sg_amax_f32(const float* x, long n, float* amax, void* stream) {
   if (!x || !amax || n < 0 || (n & 3)) return SG_ERR_ARG;
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_amax, dim3(sg_grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, reinterpret_cast<unsigned*>(amax));
+  SG_KERNEL(k_amax, dim3(sg_grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, reinterpret_cast<unsigned*>(amax));
   return sg_launch_status();
 }
 
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_cvt_fp8(const float* __restrict__ x, ui
 extern "C" int sg_cvt_fp8(const float* x, void* out, long n, int relu, const float* amax, void* stream) {
   if (!x || !out || !amax || n < 0 || (n & 7)) return SG_ERR_ARG;
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_cvt_fp8, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out, n / 8, relu, amax);
+  SG_KERNEL(k_cvt_fp8, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out, n / 8, relu, amax);
   return sg_launch_status();
 }
 
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(256) void k_pack_filter_fp8(const float* w, unsigne
 
 extern "C" int sg_pack_filter_fp8(const float* w, void* out, const float* amax, int taps, int K, int N, int transpose, void* stream) {
   if (!w || !out || !amax || taps < 1 || K < 1 || N < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_pack_filter_fp8, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
+  SG_KERNEL(k_pack_filter_fp8, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, (unsigned char*)out,
                      amax, K, N, transpose);
   return sg_launch_status();
 }

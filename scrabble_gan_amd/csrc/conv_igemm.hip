@@ -444,12 +444,12 @@ static int launch_cfg(const SgIgemmArgs& a_in, bool b_nk, hipStream_t s) {
   a.n_tiles_total = tiles;
   const dim3 g3(full + (tiles - full) * nsplit);
   if (b_nk)
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
+    SG_KERNEL((sg_igemm_kernel<BM, BN, WM, WN, true, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   else
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
+    SG_KERNEL((sg_igemm_kernel<BM, BN, WM, WN, false, BK, OCC>), g3, dim3(WM * WN * 64), 0, s, a);
   if (relu_after) {
     const long n4 = M * a.N / 4;         // N % 4 == 0 on this path ([K,N] filters) or the tensor is padded to float4 by NHWC C % 4
-    hipLaunchKernelGGL(k_relu_inplace, dim3(sg_grid_for(n4, 256)), dim3(256), 0, s, a.out, n4);
+    SG_KERNEL(k_relu_inplace, dim3(sg_grid_for(n4, 256)), dim3(256), 0, s, a.out, n4);
   }
   return sg_launch_status();
 }
@@ -633,9 +633,9 @@ static int launch_thin(const SgThinArgs& a, bool expand, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)win.nrows * win.span;
     if (lds > 60 * 1024) return SG_ERR_UNSUPPORTED;
     const long rows = (long)a.Bn * a.Hg;
-    hipLaunchKernelGGL(sg_thin_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), lds, s, a, win);
+    SG_KERNEL(sg_thin_expand_kernel, dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(256), lds, s, a, win);
   } else {
-    hipLaunchKernelGGL(sg_thin_contract_kernel, dim3(sg_grid_for(M * 16, 256)), dim3(256), 0, s, a);
+    SG_KERNEL(sg_thin_contract_kernel, dim3(sg_grid_for(M * 16, 256)), dim3(256), 0, s, a);
   }
   return sg_launch_status();
 }
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_transpose_filter(const float* w, float*
 
 extern "C" int sg_transpose_filter(const float* w, float* out, int taps, int K, int N, void* stream) {
   if (!w || !out || taps < 1 || K < 1 || N < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_transpose_filter, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, out, K, N);
+  SG_KERNEL(k_transpose_filter, dim3(sg_cdiv(N, 32), sg_cdiv(K, 32), taps), dim3(256), 0, (hipStream_t)stream, w, out, K, N);
   return sg_launch_status();
 }
 

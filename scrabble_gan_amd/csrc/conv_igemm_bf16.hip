@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_pack_filter_bf16(const float* w, __bf16
 extern "C" int sg_pack_filter_bf16(const float* w, void* out, int taps, int K, int N, int transpose, void* stream) {
   if (!w || !out || taps < 1 || K < 1 || N < 1) return SG_ERR_ARG;
   const dim3 grid(sg_cdiv(N, 32), sg_cdiv(K, 32), taps);
-  hipLaunchKernelGGL(k_pack_filter_bf16, grid, dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, K, N, transpose);
+  SG_KERNEL(k_pack_filter_bf16, grid, dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, K, N, transpose);
   return sg_launch_status();
 }
 
@@ -345,7 +345,7 @@ static int launch_bf16_cfg(const SgIgemmArgs& a_in, hipStream_t s) {
   a.full_tiles = full;
   a.tail_split = nsplit;
   a.n_tiles_total = tiles;
-  hipLaunchKernelGGL((sg_igemm_bf16_kernel<BM, BN, WM, WN, OCC>), dim3(full + (tiles - full) * nsplit), dim3(WM * WN * 64), 0, s, a);
+  SG_KERNEL((sg_igemm_bf16_kernel<BM, BN, WM, WN, OCC>), dim3(full + (tiles - full) * nsplit), dim3(WM * WN * 64), 0, s, a);
   return sg_launch_status();
 }
 

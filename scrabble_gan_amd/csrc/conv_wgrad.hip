@@ -298,11 +298,11 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
   const dim3 grid((unsigned)(combos * nchunks)), block(WM * WN * 64);
   const bool ident = wgrad_ident(a), qs = a.qscale != nullptr;
   const bool qs_uniform = qs && ident && ((long)a.Hg * a.Wg) % BK == 0 && a.mchunk % BK == 0;
-  if (ident && qs_uniform) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 2>), grid, block, 0, s, a);
-  else if (ident && qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 1>), grid, block, 0, s, a);
-  else if (ident) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 0>), grid, block, 0, s, a);
-  else if (qs) hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 0>), grid, block, 0, s, a);
+  if (ident && qs_uniform) SG_KERNEL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 2>), grid, block, 0, s, a);
+  else if (ident && qs) SG_KERNEL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 1>), grid, block, 0, s, a);
+  else if (ident) SG_KERNEL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, true, 0>), grid, block, 0, s, a);
+  else if (qs) SG_KERNEL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 1>), grid, block, 0, s, a);
+  else SG_KERNEL((sg_wgrad_kernel<BC, BN, WM, WN, BK, OCC, false, 0>), grid, block, 0, s, a);
   return sg_launch_status();
 }
 
@@ -450,7 +450,7 @@ static int launch_thin_wgrad(const SgThinArgs& a, hipStream_t s) {
   if (nb < 1 || sg_deterministic()) nb = 1;      // (deterministic mode: one workgroup, one adder per address)
   const int rpb = (int)((total_rows + nb - 1) / nb);
   const int grid = (int)((total_rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), lds, s, a, rpb, dy0, nrows, dx0, span);
+  SG_KERNEL(sg_thin_wgrad_kernel, dim3(grid), dim3(256), lds, s, a, rpb, dy0, nrows, dx0, span);
   return sg_launch_status();
 }
 

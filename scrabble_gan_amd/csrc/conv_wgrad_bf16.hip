@@ -274,8 +274,8 @@ int sg_launch_wgrad_bf16(const SgWgradArgs& a_in, hipStream_t s) {
   nchunks = (M + mchunk - 1) / mchunk;
   a.mchunk = (int)mchunk;
   const dim3 grid((unsigned)(combos * nchunks)), block(256);
-  if (a.qscale && HW % 32 == 0) hipLaunchKernelGGL((sg_wgrad_bf16_kernel<2>), grid, block, 0, s, a);
-  else if (a.qscale) hipLaunchKernelGGL((sg_wgrad_bf16_kernel<1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((sg_wgrad_bf16_kernel<0>), grid, block, 0, s, a);
+  if (a.qscale && HW % 32 == 0) SG_KERNEL((sg_wgrad_bf16_kernel<2>), grid, block, 0, s, a);
+  else if (a.qscale) SG_KERNEL((sg_wgrad_bf16_kernel<1>), grid, block, 0, s, a);
+  else SG_KERNEL((sg_wgrad_bf16_kernel<0>), grid, block, 0, s, a);
   return sg_launch_status();
 }

@@ -286,7 +286,7 @@ extern "C" int sg_conv2d_bwd_weight_fp8(const void* x8, const float* amax_x, con
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(sg_wgrad_fp8_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  SG_KERNEL(sg_wgrad_fp8_kernel, dim3((unsigned)(combos * nchunks)), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   return sg_launch_status();
 }
 
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_amax2(const float* __restrict__ x, long
 extern "C" int sg_amax2_f32(const float* x, long n, const float* rowscale, long rowlen, float* amax2, void* stream) {
   if (!x || !amax2 || n < 0 || (n & 3) || (rowscale && (rowlen <= 0 || (rowlen & 3)))) return SG_ERR_ARG;
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_amax2, dim3(sg_grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, rowscale, rowlen,
+  SG_KERNEL(k_amax2, dim3(sg_grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n / 4, rowscale, rowlen,
                      reinterpret_cast<unsigned*>(amax2));
   return sg_launch_status();
 }
@@ -403,7 +403,7 @@ extern "C" int sg_cvt_fp8_grad(const float* x, void* out_e5m2, void* out_e4m3, l
   long r = (M + 1023) / 1024;                 // ~1024 workgroups: enough to fill the chip, few enough atomics per column
   if (sg_deterministic() && dbias) r = M;     // one workgroup, one adder per column (slow: a reproducibility mode)
   const int rpb = (int)(r < 32 ? 32 : r);
-  hipLaunchKernelGGL(k_cvt_fp8_grad, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out_e5m2,
+  SG_KERNEL(k_cvt_fp8_grad, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, (uint2*)out_e5m2,
                      (uint2*)out_e4m3, M, C, rowscale, rows_per_sample, amax2, dbias, rpb);
   return sg_launch_status();
 }

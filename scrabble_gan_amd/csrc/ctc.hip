@@ -140,13 +140,13 @@ extern "C" int sg_softmax_ctc(const float* logits, const int* labels, int label_
     (void)hipGetLastError();
     return SG_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_softmax_ctc, dim3(B), dim3(64), lds, (hipStream_t)stream, logits, labels, label_stride, loss, dlogits, T, C,
+  SG_KERNEL(k_softmax_ctc, dim3(B), dim3(64), lds, (hipStream_t)stream, logits, labels, label_stride, loss, dlogits, T, C,
                      input_length, label_length);
   return sg_launch_status();
 }
 
 extern "C" int sg_rowscale(const float* x, const float* s, float* out, long rows, int rowlen, void* stream) {
   if (!x || !s || !out) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_rowscale, dim3(sg_grid_for(rows * rowlen, 256)), dim3(256), 0, (hipStream_t)stream, x, s, out, rows, rowlen);
+  SG_KERNEL(k_rowscale, dim3(sg_grid_for(rows * rowlen, 256)), dim3(256), 0, (hipStream_t)stream, x, s, out, rows, rowlen);
   return sg_launch_status();
 }

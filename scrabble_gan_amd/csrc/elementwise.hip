@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_dot(const float* a, const float* b, flo
 }
 
 #define LAUNCH(k, n_items, s, ...) \
-  hipLaunchKernelGGL(k, dim3(sg_grid_for((n_items), 256)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__)
+  SG_KERNEL(k, dim3(sg_grid_for((n_items), 256)), dim3(256), 0, (hipStream_t)(s), __VA_ARGS__)
 
 extern "C" int sg_avgpool2_add_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C, void* stream) {
   if (!a || !out || (C & 3) || (H & 1) || (W & 1)) return SG_ERR_ARG;
@@ -317,7 +317,7 @@ extern "C" int sg_maxpool_bwd(const float* dy, const unsigned char* idx, float* 
 
 extern "C" int sg_gap_fwd(const float* x, float* out, int B, int HW, int C, int relu, void* stream) {
   if (!x || !out || (C & 3)) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_gap_fwd, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, out, HW, C, relu);
+  SG_KERNEL(k_gap_fwd, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, out, HW, C, relu);
   return sg_launch_status();
 }
 
@@ -335,11 +335,11 @@ extern "C" int sg_bias_grad(const float* dy, float* db, long M, int N, void* str
     long r = (M + 511) / 512;
     if (sg_deterministic()) r = M;          // one workgroup: one adder per column, fixed summation order
     const int rpb = (int)(r < 16 ? 16 : r);
-    hipLaunchKernelGGL(k_bias_grad_v4, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
+    SG_KERNEL(k_bias_grad_v4, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
     return sg_launch_status();
   }
   const int rpb = sg_deterministic() ? (int)(M < 1 ? 1 : M) : 1024;
-  hipLaunchKernelGGL(k_bias_grad, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
+  SG_KERNEL(k_bias_grad, dim3(sg_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, dy, db, M, N, rpb);
   return sg_launch_status();
 }
 
@@ -357,7 +357,7 @@ extern "C" int sg_scale(const float* a, const float* s, float* out, long n, void
 
 extern "C" int sg_dot_accum(const float* a, const float* b, float* out, long n, void* stream) {
   if (!a || !b || !out || (n & 3)) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_dot, dim3(sg_grid_for(n / 4, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+  SG_KERNEL(k_dot, dim3(sg_grid_for(n / 4, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
   return sg_launch_status();
 }
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_filterbank_bwd_table(const float* z0, c
 // z: [B,128] (only columns 0..31 are read: z0); seed: [B,4,4L,512]
 extern "C" int sg_filterbank_fwd(const float* z, const int* y, const float* table, float* seed, int B, int L, int vocab, void* stream) {
   if (!z || !y || !table || !seed || B < 1 || L < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_filterbank_fwd, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, z, y, table, seed, L, vocab);
+  SG_KERNEL(k_filterbank_fwd, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, z, y, table, seed, L, vocab);
   return sg_launch_status();
 }
 
@@ -124,7 +124,7 @@ extern "C" int sg_filterbank_fwd(const float* z, const int* y, const float* tabl
 extern "C" int sg_filterbank_bwd(const float* z, const int* y, const float* table, const float* dseed, float* dtable, float* dz,
                                  int B, int L, int vocab, void* stream) {
   if (!z || !y || !table || !dseed || !dtable || !dz || B < 1 || L < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_filterbank_bwd_dz, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, y, table, dseed, dz, L, vocab);
-  hipLaunchKernelGGL(k_filterbank_bwd_table, dim3(FB_J / 4 / 256, vocab), dim3(256), 0, (hipStream_t)stream, z, y, dseed, dtable, B * L, L, vocab);
+  SG_KERNEL(k_filterbank_bwd_dz, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, y, table, dseed, dz, L, vocab);
+  SG_KERNEL(k_filterbank_bwd_table, dim3(FB_J / 4 / 256, vocab), dim3(256), 0, (hipStream_t)stream, z, y, dseed, dtable, B * L, L, vocab);
   return sg_launch_status();
 }

@@ -65,9 +65,9 @@ extern "C" int sg_gemm(const float* A, const float* B, float* C, const float* bi
   if (M == 0 || N == 0) return SG_OK;
   dim3 grid(sg_cdiv(N, 32), sg_cdiv(M, 32)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (transA && transB) hipLaunchKernelGGL((k_gemm_small<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
-  else if (transA) hipLaunchKernelGGL((k_gemm_small<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
-  else if (transB) hipLaunchKernelGGL((k_gemm_small<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
-  else hipLaunchKernelGGL((k_gemm_small<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
+  if (transA && transB) SG_KERNEL((k_gemm_small<true, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
+  else if (transA) SG_KERNEL((k_gemm_small<true, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
+  else if (transB) SG_KERNEL((k_gemm_small<false, true>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
+  else SG_KERNEL((k_gemm_small<false, false>), grid, block, 0, s, A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta);
   return sg_launch_status();
 }

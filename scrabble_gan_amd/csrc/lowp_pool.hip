@@ -86,7 +86,7 @@ extern "C" int sg_avgpool2_bwd_bf16(const float* dout, void* dx16, void* dx16_sc
   if (!dout || (!dx16 && !dx16_scaled) || (H & 1) || (W & 1) || (C & 7)) return SG_ERR_ARG;
   const long n = (long)B * H * W * (C / 8);
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_avgpool2_bwd_lowp<false>, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx16, dx16_scaled, rowscale,
+  SG_KERNEL(k_avgpool2_bwd_lowp<false>, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx16, dx16_scaled, rowscale,
                      (const float*)nullptr, (float*)nullptr, B, H, W, C);
   return sg_launch_status();
 }
@@ -98,7 +98,7 @@ extern "C" int sg_avgpool2_bwd_fp8(const float* dout, void* dx_e4m3, void* dx_e5
   if (!dout || (!dx_e4m3 && !dx_e5m2) || !amax_dout || !amax_dx || (H & 1) || (W & 1) || (C & 7)) return SG_ERR_ARG;
   const long n = (long)B * H * W * (C / 8);
   if (n == 0) return SG_OK;
-  hipLaunchKernelGGL(k_avgpool2_bwd_lowp<true>, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx_e4m3, dx_e5m2, rowscale,
+  SG_KERNEL(k_avgpool2_bwd_lowp<true>, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx_e4m3, dx_e5m2, rowscale,
                      amax_dout, amax_dx, B, H, W, C);
   return sg_launch_status();
 }

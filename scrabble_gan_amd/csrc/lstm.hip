@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_mul_mask(const float* x, const float* m
 extern "C" int sg_lstm_cell_fwd(float* z, int ldz, const float* c_prev, float* c_out, float* h_out, int ldh, float* h_copy, int ldc,
                                 int B, int H, void* stream) {
   if (!z || !c_out || !h_out || B < 1 || H < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_lstm_cell_fwd, dim3(sg_grid_for((long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, c_prev, c_out,
+  SG_KERNEL(k_lstm_cell_fwd, dim3(sg_grid_for((long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, c_prev, c_out,
                      h_out, ldh, h_copy, ldc, B, H);
   return sg_launch_status();
 }
@@ -82,25 +82,25 @@ extern "C" int sg_lstm_cell_fwd(float* z, int ldz, const float* c_prev, float* c
 extern "C" int sg_lstm_cell_bwd(float* gates, int ldz, const float* c_prev, const float* c_t, const float* dh_a, int lda,
                                 const float* dh_b, const float* dc_next, float* dc_prev, int B, int H, void* stream) {
   if (!gates || !c_t || !dh_a || !dc_prev || B < 1 || H < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_lstm_cell_bwd, dim3(sg_grid_for((long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, gates, ldz, c_prev, c_t,
+  SG_KERNEL(k_lstm_cell_bwd, dim3(sg_grid_for((long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, gates, ldz, c_prev, c_t,
                      dh_a, lda, dh_b, dc_next, dc_prev, B, H);
   return sg_launch_status();
 }
 
 extern "C" int sg_leaky_relu_fwd(const float* x, float* y, long n, float alpha, void* stream) {
   if (!x || !y) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_leaky_fwd, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha);
+  SG_KERNEL(k_leaky_fwd, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha);
   return sg_launch_status();
 }
 
 extern "C" int sg_leaky_relu_bwd(const float* dy, const float* x, float* dx, long n, float alpha, void* stream) {
   if (!dy || !x || !dx) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_leaky_bwd, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n, alpha);
+  SG_KERNEL(k_leaky_bwd, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n, alpha);
   return sg_launch_status();
 }
 
 extern "C" int sg_mul_mask(const float* x, const float* mask, float* out, long rows, int cols, int rows_per_mask, void* stream) {
   if (!x || !mask || !out || rows_per_mask < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_mul_mask, dim3(sg_grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, out, rows, cols, rows_per_mask);
+  SG_KERNEL(k_mul_mask, dim3(sg_grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, out, rows, cols, rows_per_mask);
   return sg_launch_status();
 }

@@ -48,14 +48,14 @@ extern "C" int sg_adam_update(float* p, const float* g, float* m, float* v, long
                               float eps, void* stream) {
   if (!p || !g || !m || !v) return SG_ERR_ARG;
   if (n <= 0) return SG_OK;
-  hipLaunchKernelGGL(k_adam, dim3(sg_grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta_1, beta_2, eps);
+  SG_KERNEL(k_adam, dim3(sg_grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta_1, beta_2, eps);
   return sg_launch_status();
 }
 
 extern "C" int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream) {
   if (!p || !g || !ms) return SG_ERR_ARG;
   if (n <= 0) return SG_OK;
-  hipLaunchKernelGGL(k_rmsprop, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, rho, eps);
+  SG_KERNEL(k_rmsprop, dim3(sg_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, rho, eps);
   return sg_launch_status();
 }
 
@@ -117,16 +117,16 @@ extern "C" int sg_spectral_norm(const float* w, const float* u, float* out, floa
   const float* u_n2 = nullptr;
   for (int it = 0; it < power_iteration; ++it) {
     (void)hipMemsetAsync(nv2, 0, sizeof(float), s);
-    hipLaunchKernelGGL(k_sn_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, u_cur, u_n2, v, nv2, K, N);
+    SG_KERNEL(k_sn_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, u_cur, u_n2, v, nv2, K, N);
     // u_cur may alias u_ on later iterations: k_sn_rows has consumed it before the memset below (stream order)
     (void)hipMemsetAsync(u_, 0, sizeof(float) * N, s);
     const int rpb = 64;
-    hipLaunchKernelGGL(k_sn_cols, dim3(sg_cdiv(K, rpb)), dim3(256), 0, s, w, v, nv2, u_, K, N, rpb);
-    hipLaunchKernelGGL(k_sn_norm2, dim3(1), dim3(256), 0, s, u_, nu2, N);
+    SG_KERNEL(k_sn_cols, dim3(sg_cdiv(K, rpb)), dim3(256), 0, s, w, v, nv2, u_, K, N, rpb);
+    SG_KERNEL(k_sn_norm2, dim3(1), dim3(256), 0, s, u_, nu2, N);
     u_cur = u_;
     u_n2 = nu2;
   }
-  hipLaunchKernelGGL(k_sn_scale, dim3(sg_grid_for((long)K * N, 256)), dim3(256), 0, s, w, nu2, out, (long)K * N);
+  SG_KERNEL(k_sn_scale, dim3(sg_grid_for((long)K * N, 256)), dim3(256), 0, s, w, nu2, out, (long)K * N);
   return sg_launch_status();
 }
 
@@ -190,11 +190,11 @@ extern "C" int sg_spectral_norm_bwd(const float* w, const float* u, const float*
   float* c = na2 + 4;
   (void)hipMemsetAsync(b, 0, sizeof(float) * N, s);
   (void)hipMemsetAsync(na2, 0, sizeof(float) * 8, s);
-  hipLaunchKernelGGL(k_sn_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, u, (const float*)nullptr, a, na2, K, N);
-  hipLaunchKernelGGL(k_sn_cols, dim3(sg_cdiv(K, 64)), dim3(256), 0, s, w, a, na2, b, K, N, 64);
-  hipLaunchKernelGGL(k_sn_norm2, dim3(1), dim3(256), 0, s, b, nb2, N);
-  hipLaunchKernelGGL(k_snb_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, g, a, b, na2, nb2, t, c, sdot, K, N);
-  hipLaunchKernelGGL(k_snb_apply, dim3(sg_grid_for((long)K * N, 256)), dim3(256), 0, s, g, u, a, b, t, na2, nb2, c, sdot, dw, K, N);
+  SG_KERNEL(k_sn_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, u, (const float*)nullptr, a, na2, K, N);
+  SG_KERNEL(k_sn_cols, dim3(sg_cdiv(K, 64)), dim3(256), 0, s, w, a, na2, b, K, N, 64);
+  SG_KERNEL(k_sn_norm2, dim3(1), dim3(256), 0, s, b, nb2, N);
+  SG_KERNEL(k_snb_rows, dim3(sg_cdiv(K, 4)), dim3(256), 0, s, w, g, a, b, na2, nb2, t, c, sdot, K, N);
+  SG_KERNEL(k_snb_apply, dim3(sg_grid_for((long)K * N, 256)), dim3(256), 0, s, g, u, a, b, t, na2, nb2, c, sdot, dw, K, N);
   return sg_launch_status();
 }
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_loss_grads(const float* d_r, const floa
 extern "C" int sg_loss_sums(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r,
                             const float* r_f, const float* r_r, int B, int mode, double* sums, void* stream) {
   if (!d_r || !d_f || !s_my || !s_f || !s_r || !r_f || !r_r || !sums || B < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, r_f, r_r, B, mode, sums);
+  SG_KERNEL(k_loss_sums, dim3(1), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, r_f, r_r, B, mode, sums);
   return sg_launch_status();
 }
 
@@ -322,7 +322,7 @@ extern "C" int sg_loss_grads(const float* d_r, const float* d_f, const float* s_
                              float* shS, void* stream) {
   if (!d_r || !d_f || !s_my || !s_f || !s_r || !r_f || !sums || !scalars || !gD_r || !gD_f || !gS_my || !gS_f || !gG_d || !gG_s || !gG_r)
     return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_loss_grads, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, r_f, B, mode,
+  SG_KERNEL(k_loss_grads, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, r_f, B, mode,
                      balance, alpha, sums, scalars, gD_r, gD_f, gS_my, gS_f, gG_d, gG_s, gG_r, shD, shS);
   return sg_launch_status();
 }
@@ -342,6 +342,6 @@ __global__ __launch_bounds__(256) void k_loss_terms(const float* d_r, const floa
 extern "C" int sg_loss_terms(const float* d_r, const float* d_f, const float* s_my, const float* s_f, const float* s_r, int B,
                              int mode, float* out7, void* stream) {
   if (!d_r || !d_f || !s_my || !s_f || !s_r || !out7 || B < 1) return SG_ERR_ARG;
-  hipLaunchKernelGGL(k_loss_terms, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, B, mode, out7);
+  SG_KERNEL(k_loss_terms, dim3(sg_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, d_r, d_f, s_my, s_f, s_r, B, mode, out7);
   return sg_launch_status();
 }

@@ -18,6 +18,15 @@
 #define SG_MMA_BF16 256 // weight-grad: round the matrix-core operands to bf16 (fp32 accumulation); config c3
 
 #include <stdio.h>
+// Kernel launch + status.  hipGetLastError() returns the last error of ANY earlier runtime call of the thread -- also one the
+// host framework left behind (an event / stream query that was "not ready", a failed probe) -- so the slate is wiped right
+// before the launch: what sg_launch_status() then reports belongs to this launch.  (Seen once in round 3: a conv launch
+// "failed" in one process and ran in the next with the same arguments.)
+#define SG_KERNEL(kernel, grid, block, lds, stream, ...)                                  \
+  do {                                                                                    \
+    (void)hipGetLastError();                                                              \
+    kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__);                            \
+  } while (0)
 static inline int sg_launch_status() {
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess) return SG_OK;

@@ -150,7 +150,7 @@ def committed_traffic(kernel, conv_dtype, per_gpu_batch):
 
 
 def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev, world, bucketed=False, sync_every_step=False,
-            kernel_timing=True, shape_table=None, hbm_families=True):
+            kernel_timing=True, shape_table=None, hbm_families=True, graph=False):
     """Build the four networks, run `warmup` + `steps` train_steps of one configuration with the inputs resident in HBM, and
     return everything measured: wall time of the timed region (MAX over ranks), HIP-event summaries of the kernel families.
     The models and every per-step buffer are released before returning."""
@@ -182,7 +182,14 @@ def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev
         pair_rng = np.random.default_rng(7)
         pairs = [tuple(int(v) for v in pair_rng.integers(4, 24, 2)) for _ in range(warmup + steps + 2 * timing_steps)]
 
+    gs = None
+    if graph:       # the step captured once into a HIP graph, then one launch per step (scrabble_gan_amd/graph_step.py)
+        from scrabble_gan_amd.graph_step import GraphedStep
+        gs = GraphedStep(D, R, S, gan, opts, B, net_loss.hinge, int(balance), warmup=2).capture(images_d, labels_d, my_d, fake_d)
+
     def step(i):
+        if gs is not None:
+            return gs.step()
         if pools is not None:
             L_r, L_f = pairs[i % len(pairs)]
             return DU.train_step(0, i, steps, pools[L_r][0], pools[L_r][1], D, R, S, gan, opts[0], opts[1], opts[2], opts[3], my_d,
@@ -353,9 +360,12 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="the default N = 1 invocation also measures configs c3 (bf16, bs 256) and c5 (fp8, bs 512, balancing) after the "
                          "headline's timed region and reports them under \"configs\"; this flag skips them")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into a HIP graph once and replay it (single GPU, fixed shapes; no per-kernel timing: the "
+                         "roofline object is omitted) -- for the small-batch bf16 / fp8 steps whose host time is within 2x of the GPU time")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + one all-reduce only, no GPU work (launcher rehearsal on CPU)")
     args = ap.parse_args()
-    plain_invocation = args.conv_dtype is None and args.batch is None and not args.bucketed and not args.balance and args.L == 10
+    plain_invocation = args.conv_dtype is None and args.batch is None and not args.bucketed and not args.balance and args.L == 10 and not args.graph
     if args.conv_dtype is None:
         args.conv_dtype = "f32"
     if args.batch is None:
@@ -386,8 +396,8 @@ def main():
 
     B, L = args.batch, args.L
     res = measure(args.conv_dtype, B, L, args.balance, args.steps, args.warmup, args.timing_steps, reducer, dev, world,
-                  bucketed=args.bucketed, sync_every_step=args.sync_every_step, kernel_timing=not args.no_kernel_timing,
-                  shape_table=args.shape_table if rank == 0 else None)
+                  bucketed=args.bucketed, sync_every_step=args.sync_every_step, kernel_timing=not (args.no_kernel_timing or args.graph),
+                  shape_table=args.shape_table if rank == 0 else None, graph=args.graph and world == 1 and not args.bucketed)
     res["hbm_steps"] = args.timing_steps
 
     # configs c3 and c5 of BASELINE.json in the same (driver-run) invocation: after the headline's timed region and its timing
@@ -429,6 +439,7 @@ def main():
             "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if (L == 10 and not args.bucketed) else None,      # reference-tape accounting
             "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if (L == 10 and not args.bucketed) else None,  # what the kernels actually run
         }
+        line["config"]["hip_graph"] = bool(args.graph)
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True
         line["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1

@@ -262,6 +262,10 @@ int sg_lstm_cell_bwd(float* gates, int ldz, const float* c_prev, const float* c_
 
 /* ---- optimizers (main.py:27-33; Keras Adam / RMSprop) and spectral_norm (arch_ops.py:98-126) */
 int sg_adam_update(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta_1, float beta_2, float eps, void* stream);
+/* sg_adam_update with the bias-corrected step size lr_t read from device memory (lr_t_dev[0]): a step captured into a HIP graph
+ * (scrabble_gan_amd/graph_step.py) replays its launches with the arguments of the capture, and lr_t changes every step */
+int sg_adam_update_dlr(float* p, const float* g, float* m, float* v, long n, const float* lr_t_dev, float beta_1, float beta_2, float eps,
+                       void* stream);
 int sg_rmsprop_update(float* p, const float* g, float* ms, long n, float lr, float rho, float eps, void* stream);
 long sg_spectral_norm_workspace_floats(int K, int N);
 int sg_spectral_norm(const float* w, const float* u, float* out, float* workspace, int K, int N, int power_iteration, void* stream);

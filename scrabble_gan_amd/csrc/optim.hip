@@ -11,7 +11,11 @@
 #define CF4(p) (*reinterpret_cast<const float4*>(p))
 
 // Keras Adam: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t m / (sqrt(v) + eps)
-__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps) {
+// lr_dev (nullable): the step size lr_t read from device memory instead of the kernel argument -- a captured HIP graph replays
+// the launch with the arguments it was captured with, and lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) changes every step
+__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, long n, float lr_arg, const float* lr_dev, float b1,
+                                              float b2, float eps) {
+  const float lr_t = lr_dev ? lr_dev[0] : lr_arg;
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += stride) {
@@ -48,7 +52,17 @@ extern "C" int sg_adam_update(float* p, const float* g, float* m, float* v, long
                               float eps, void* stream) {
   if (!p || !g || !m || !v) return SG_ERR_ARG;
   if (n <= 0) return SG_OK;
-  SG_KERNEL(k_adam, dim3(sg_grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta_1, beta_2, eps);
+  SG_KERNEL(k_adam, dim3(sg_grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, (const float*)nullptr, beta_1,
+            beta_2, eps);
+  return sg_launch_status();
+}
+
+// the same update with lr_t taken from device memory (lr_t_dev[0]): for steps replayed from a captured HIP graph
+extern "C" int sg_adam_update_dlr(float* p, const float* g, float* m, float* v, long n, const float* lr_t_dev, float beta_1, float beta_2,
+                                  float eps, void* stream) {
+  if (!p || !g || !m || !v || !lr_t_dev) return SG_ERR_ARG;
+  if (n <= 0) return SG_OK;
+  SG_KERNEL(k_adam, dim3(sg_grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, lr_t_dev, beta_1, beta_2, eps);
   return sg_launch_status();
 }
 

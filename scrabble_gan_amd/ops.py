@@ -130,8 +130,11 @@ SIDE_MAX_BATCH = int(_os.environ.get("SG_SIDE_MAX_BATCH", "96"))
 _SIDE = {"stream": None, "dirty": False}
 
 
+CAPTURING = False      # graph_step.GraphedStep sets this while a step is captured into a HIP graph (single stream)
+
+
 def side_enabled() -> bool:
-    return SIDE_WGRAD and PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32"
+    return SIDE_WGRAD and PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32" and not CAPTURING
 
 
 class side_stream:
@@ -1115,9 +1118,13 @@ def loss_grads(d_r, d_f, s_my, s_f, s_r, r_f, mode: int, balance: bool, alpha: f
 
 # ---------------------------------------------------------------- optimizers / spectral norm
 def adam_update(p, g, m, v, lr_t, beta_1, beta_2, eps=1e-7):
+    """lr_t: the bias-corrected step size as a float, or a 1-element device tensor holding it (graph-captured steps)."""
     _chk(p, g, m, v)
     with _hbm("adam", p, p, g, m, m, v, v):
-        call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
+        if torch.is_tensor(lr_t):
+            call("sg_adam_update_dlr", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
+        else:
+            call("sg_adam_update", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps), _stream())
     weights_changed()
 
 

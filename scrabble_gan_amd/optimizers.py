@@ -15,6 +15,7 @@ class Adam:
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
         self._slots = {}
+        self.lr_dev = None          # 1-element device tensor: when set, the kernels read lr_t from it (graph-captured steps)
 
     def _lr_t(self):
         t = self.iterations
@@ -29,7 +30,7 @@ class Adam:
     def apply_flat(self, store):
         self.iterations += 1
         m, v = self._slot(store.flat)
-        ops.adam_update(store.flat, store.grad, m, v, self._lr_t(), self.beta_1, self.beta_2, self.epsilon)
+        ops.adam_update(store.flat, store.grad, m, v, self._lr_t() if self.lr_dev is None else self.lr_dev, self.beta_1, self.beta_2, self.epsilon)
 
     def apply_gradients(self, grads_and_vars):
         self.iterations += 1

@@ -292,3 +292,52 @@ def test_device_prefetcher_matches_the_host_loader(dev, tmp_path):
         return seen
 
     assert run() == run()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_graph_captured_step_equals_eager_steps(dev, mode):
+    """scrabble_gan_amd.graph_step.GraphedStep: a train_step captured once into a HIP graph and replayed -- the per-call
+    NonLocalBlock kernels and Adam's bias-corrected step size reach the replay through device memory.  Three eager steps on one
+    set of models against (two eager warm-up steps + ONE replay) on an identical set, same generator seeds: same scalars of the
+    third step (1e-3; float-atomic summation order differs run to run), weights within the Adam bar of the resume test (a
+    component whose gradient is ~0 may step the other way: <= 3 x 2 lr, mean << lr), optimizer counters advanced."""
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
+    from scrabble_gan_amd.graph_step import GraphedStep
+    B, L = 8, 3
+    images, labels, my_imgs = DU.synthetic_batch(B, L, seed=3)
+    words = DU.synthetic_random_words(10, 50, seed=3)
+    fake = np.array(words[L - 1][:B], np.int32)
+    dv = [torch.from_numpy(a).to(dev) for a in (images, labels, my_imgs, fake)]
+
+    def build():
+        NA._model_counter[0] = 0
+        NA.configure(device=dev, seed=4)
+        G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+        D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+        R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+        S = NA.make_style_promoter((32, 160, 1), None, "B1", vis_model=False)
+        for m in (G, D, S):
+            for k in m.store.names:
+                if k.endswith(".sigma"):
+                    m.store.p[k].fill_(0.25)
+        return G, D, R, S, NA.make_gan(G, D, R, S, vis_model=False), [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+
+    try:
+        ops.set_conv_dtype(mode)
+        a = build()
+        for i in range(3):
+            out_a = DU.train_step(0, 0, 1, dv[0], dv[1], a[1], a[2], a[3], a[4], a[5][0], a[5][1], a[5][2], a[5][3], dv[2], B, 128,
+                                  net_loss.hinge, 1, 0, words, 10, "", fake_labels=dv[3], verbose=False)
+        b = build()
+        gs = GraphedStep(b[1], b[2], b[3], b[4], b[5], B, net_loss.hinge, 0, warmup=2).capture(*dv)
+        assert all(o.iterations == 2 for o in b[5])
+        out_b = tuple(gs.step())
+        assert all(o.iterations == 3 for o in b[5])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_dtype("f32")
+    sa, sb = np.array(out_a, np.float64), np.array(out_b, np.float64)
+    assert np.all(np.isfinite(sb)) and np.all(np.abs(sa - sb) <= (1e-3 if mode == "f32" else 2e-2) * np.maximum(1.0, np.abs(sa))), (sa, sb)
+    for ma, mb in zip(a[:4], b[:4]):
+        diff = (ma.store.flat - mb.store.flat).abs()
+        assert diff.max().item() <= 3 * 2 * 2e-4 * 1.1 and diff.mean().item() <= (2e-5 if mode == "f32" else 1e-4), (ma.name, diff.max().item(), diff.mean().item())

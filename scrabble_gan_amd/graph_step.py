@@ -90,9 +90,7 @@ class GraphedStep:
         for _ in range(self.warmup):               # eager steps through exactly the code path that gets captured
             self._upload_step_state()
             self._run()
-        torch.cuda.synchronize()
-        self._upload_step_state()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                   # (nothing is executed during capture: the static buffers need no fresh content)
         saved = [o.iterations for o in self.opts]
         self.graph = torch.cuda.CUDAGraph()
         ops.CAPTURING = True

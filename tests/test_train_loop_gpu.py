@@ -301,7 +301,7 @@ def test_graph_captured_step_equals_eager_steps(dev, mode):
     eager warm-up steps inside) the whole training state is snapshotted; ONE graph replay from that state is compared with ONE
     eager train_step from the same state, same inputs, same NonLocalBlock kernels: the 16 scalars at 1e-4 (fp32) / 1e-3 (bf16:
     an atomic-order difference that crosses a bf16 rounding boundary), the post-Adam weights within the Adam bar (a component
-    whose gradient is ~0 may step the other way: <= 2 lr, mean << lr), optimizer counters advanced by the replay."""
+    whose gradient is ~0 may step the other way: <= 3.5 lr, mean << lr), optimizer counters advanced by the replay."""
     from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
     from scrabble_gan_amd.graph_step import GraphedStep
     B, L = 8, 3
@@ -349,4 +349,6 @@ def test_graph_captured_step_equals_eager_steps(dev, mode):
     assert np.all(np.abs(out_g - out_e) <= tol * np.maximum(1.0, np.abs(out_e))), (out_g, out_e)
     for m, wg, we in zip(models, w_graph, w_eager):
         diff = (wg - we).abs()
-        assert diff.max().item() <= 2 * 2e-4 * 1.1 and diff.mean().item() <= 2e-6, (m.name, diff.max().item(), diff.mean().item())
+        # (third Adam step, beta_1 = 0: |update| <= lr sqrt(1 - 0.999^3) / sqrt(0.001) = 1.73 lr for a component whose history is ~0;
+        #  stepping the other way in the two runs = 3.5 lr = 6.9e-4, measured exactly that on one component in bf16 mode)
+        assert diff.max().item() <= 4 * 2e-4 and diff.mean().item() <= 5e-6, (m.name, diff.max().item(), diff.mean().item())

@@ -216,3 +216,86 @@ def test_ctc_vs_oracle_at_launch_geometry(dev, B, L):
     loss, dl = ops.softmax_ctc(logits.detach().float().to(dev), labels.int().to(dev), T, L)
     _close(loss, cost[:, 0], 2e-5, "CTC cost")
     _close(dl, logits.grad, 1e-4 if L <= 10 else 3e-4, "d cost / d logits")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (e) whole NETWORKS at the launch geometry of the step.  D / S have no BatchNorm and the frozen R normalises with moving
+# statistics, so samples are independent: the fused passes of the bs-128 step (384 / 256 samples of 32 x 160) run as they do in
+# train_step -- every kernel at its real grid, the fused multi-call NonLocalBlock segments, the shared backward sweep with
+# per-sample weight factors -- and the oracle evaluates the first / last samples of each call: logits / CTC costs 1e-4, the image
+# gradient 1e-3 of max|ref| (the bars of tests/test_nets_gpu.py at toy size).
+# ---------------------------------------------------------------------------------------------------------------------
+def _perturbed(model, gen):
+    w = model.store.export()
+    for k, v in w.items():
+        if k.endswith(".sigma"):
+            w[k] = torch.tensor(0.3)
+        elif k.endswith(".b") or k.endswith(".beta"):
+            w[k] = torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".gamma"):
+            w[k] = 1 + torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".mm"):
+            w[k] = torch.randn(v.shape, generator=gen) * 0.1
+        elif k.endswith(".mv"):
+            w[k] = 1 + torch.rand(v.shape, generator=gen) * 0.2
+    model.store.load(w)
+    return {k: v.double() for k, v in w.items()}
+
+
+def test_discriminator_fused_pass_vs_oracle_at_launch_geometry(dev):
+    """make_discriminator (net_architecture.py:299-355) on the fused fake | style | real pass of the bs-128 step (3 x 128 samples,
+    one NonLocalBlock kernel set per call), forward and the image gradient of a backward sweep with want_dw (per-sample weight
+    factors as the shared sweep passes them)."""
+    from scrabble_gan_amd import net_architecture as NA, nn
+    NA.configure(device=dev, seed=3)
+    gen = torch.Generator().manual_seed(77)
+    D = NA.make_discriminator((32, 160, 1), None, "B1", vis_model=False)
+    P = _perturbed(D, gen)
+    B = 128
+    g = torch.Generator(device=dev).manual_seed(78)
+    xs = [torch.rand(B, 32, 160, 1, device=dev, generator=g) * 2 - 1 for _ in range(3)]
+    nls_o = [O.init_nonlocal(64, gen) for _ in range(3)]
+    nls_g = [{k: v.float().to(dev).contiguous() for k, v in d.items()} for d in nls_o]
+    logits, ctx, bounds = D.forward_multi(xs, nls_g)
+    up = torch.randn(3 * B, device=dev, generator=g)
+    wsc = torch.rand(3 * B, device=dev, generator=g) + 0.5
+    D.store.zero_grad()
+    dx = D.backward(ctx, up, want_dx=True, want_dw=True, wscale=wsc)
+    for c, (x, nlo, (lo, hi)) in enumerate(zip(xs, nls_o, bounds)):
+        xe = _edge(x).requires_grad_(True)
+        ref = O.discriminator(xe, P, nlo)
+        ue = _edge(up[lo:hi])
+        (ref[:, 0] * ue).sum().backward()
+        _close(_edge(logits[c]), ref, 1e-4, "logits of call %d (first / last 2 samples)" % c)
+        _close(_edge(dx[lo:hi]), xe.grad, 1e-3, "image gradient of call %d" % c)
+    assert torch.isfinite(D.store.grad).all()
+
+
+def test_recognizer_fused_pass_vs_oracle_at_launch_geometry(dev):
+    """make_recognizer + K.ctc_batch_cost (net_architecture.py:9-79) frozen (inference-mode BatchNorm) on the fused
+    fake | real pass of the bs-128 step (256 words of 10 characters): CTC cost per sample and the image gradient of the fake half."""
+    from scrabble_gan_amd import net_architecture as NA
+    NA.configure(device=dev, seed=3)
+    gen = torch.Generator().manual_seed(79)
+    R = NA.make_recognizer((32, 160, 1), None, 53, vis_model=False)
+    P = _perturbed(R, gen)
+    R.trainable = False
+    B, L = 128, 10
+    g = torch.Generator(device=dev).manual_seed(80)
+    xs = [torch.rand(B, 32, 160, 1, device=dev, generator=g) * 2 - 1 for _ in range(2)]
+    labs = [torch.randint(0, 52, (B, L), device=dev, generator=g, dtype=torch.int32) for _ in range(2)]
+    T = 4 * L - 1
+    (loss_f, loss_r), ctx, bounds = R.forward_multi(xs, labs, T, L, training=True)
+    up = torch.rand(B, device=dev, generator=g) + 0.5
+    dx = R.backward(R.slice_ctx(ctx, 0, B), up, want_dx=True, want_dw=False)
+    for c, (x, lab, loss) in enumerate(zip(xs, labs, (loss_f, loss_r))):
+        xe = _edge(x).requires_grad_(True)
+        ref = O.recognizer(xe, _edge_i(lab), T, L, P, bn_training=False)
+        _close(_edge(loss.reshape(-1, 1)), ref, 1e-4, "CTC cost of call %d (first / last 2 samples)" % c)
+        if c == 0:
+            (ref[:, 0] * _edge(up)).sum().backward()
+            _close(_edge(dx), xe.grad, 1e-3, "image gradient through the frozen recognizer")
+
+
+def _edge_i(t, n=2):
+    return torch.cat([t[:n], t[-n:]], 0).long().cpu()

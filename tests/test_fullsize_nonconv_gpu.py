@@ -31,6 +31,12 @@ def _edge(t, n=2):
     return torch.cat([t[:n], t[-n:]], 0).double().cpu()
 
 
+def _close_l2(got, ref, tol, name):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    err, scale = (got - ref).norm().item(), ref.norm().item() + 1e-30
+    assert err <= tol * scale, "%s: ||err|| %.3e vs ||ref|| %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (a) attention of NonLocalBlock (arch_ops.py:51-61).  G.NL3 at L = 10 is the largest attention launch of the step:
 # Nq = 32*160 = 5120 queries, Nk = 1280 keys per sample; L = 23: 11776 x 2944.  The discriminator-side site (1280 x 320)
@@ -267,7 +273,8 @@ def test_discriminator_fused_pass_vs_oracle_at_launch_geometry(dev):
         ue = _edge(up[lo:hi])
         (ref[:, 0] * ue).sum().backward()
         _close(_edge(logits[c]), ref, 1e-4, "logits of call %d (first / last 2 samples)" % c)
-        _close(_edge(dx[lo:hi]), xe.grad, 1e-3, "image gradient of call %d" % c)
+        _close(_edge(dx[lo:hi]), xe.grad, 3e-3, "image gradient of call %d" % c)      # (|dx| ~ 1e-4: fp32 through 10 layers; measured 1.2e-3)
+        _close_l2(_edge(dx[lo:hi]), xe.grad, 1e-3, "image gradient of call %d (L2)" % c)
     assert torch.isfinite(D.store.grad).all()
 
 
@@ -294,7 +301,11 @@ def test_recognizer_fused_pass_vs_oracle_at_launch_geometry(dev):
         _close(_edge(loss.reshape(-1, 1)), ref, 1e-4, "CTC cost of call %d (first / last 2 samples)" % c)
         if c == 0:
             (ref[:, 0] * _edge(up)).sum().backward()
-            _close(_edge(dx), xe.grad, 1e-3, "image gradient through the frozen recognizer")
+            # dx crosses 4 max-pools and 7 ReLU masks over 1.3 M activations per sample: a near-tie resolved differently in
+            # fp32 re-routes single pixels (measured: max 1.2e-2 of max|ref| at a handful of pixels) -- the whole gradient is
+            # held in the L2 norm at 1e-3, single pixels at 3e-2 (tests/test_nets_gpu.py::test_recognizer: 5e-3 at 32 x 48)
+            _close_l2(_edge(dx), xe.grad, 1e-3, "image gradient through the frozen recognizer (L2)")
+            _close(_edge(dx), xe.grad, 3e-2, "image gradient through the frozen recognizer")
 
 
 def _edge_i(t, n=2):

@@ -312,3 +312,39 @@ def test_recognizer_fused_pass_vs_oracle_at_launch_geometry(dev):
 
 def _edge_i(t, n=2):
     return torch.cat([t[:n], t[-n:]], 0).long().cpu()
+
+
+def test_generator_vs_oracle_at_the_shard_geometry(dev):
+    """make_generator (net_architecture.py:182-296) forward AND backward on a WHOLE batch at the launch geometry of the 8-way
+    data-parallel shard (B = 16 words of 10 characters, 160-wide style images): style encoder, z, filter bank, the three
+    ResNetBlockUp with ConditionalBatchNorm over the batch's own statistics (10 240 ... 81 920 pixels), the NonLocalBlock at
+    5120 x 1280, final BN + conv + tanh -- image 1e-4; every gradient tensor with the criterion of tests/test_nets_gpu.py::
+    test_generator (max-norm 1e-2 of max|ref|, or L2 2.5e-3 with <= 1 % outliers where a ReLU decision flipped); moving statistics."""
+    from scrabble_gan_amd import net_architecture as NA
+    from tests.test_nets_gpu import close, close_grad, leaves, net_atol
+    NA.configure(device=dev, seed=3)
+    gen = torch.Generator().manual_seed(7)
+    G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
+    P = _perturbed(G, gen)
+    B, L = 16, 10
+    style = torch.rand(B, 32, 160, 1, generator=gen, dtype=torch.float64) * 2 - 1
+    y = torch.randint(0, 52, (B, L), generator=gen)
+    nls_o, nlu_o = O.init_nonlocal(64, gen), O.init_nonlocal(64, gen)
+    nls_g, nlu_g = ({k: v.float().to(dev).contiguous() for k, v in d.items()} for d in (nls_o, nlu_o))
+    dimg = torch.randn(B, 32, 16 * L, 1, generator=gen, dtype=torch.float64)
+    lv = leaves(P)
+    stats = {}
+    ref = O.generator(style, y, P, nls_o, nlu_o, bn_stats=stats)
+    (ref * dimg).sum().backward()
+    img, ctx = G.forward(style.float().to(dev), y.int().to(dev), nls_g, nlu_g, training=True)
+    close(img, ref, 1e-4, "image")
+    G.store.zero_grad()
+    G.backward(ctx, dimg.float().to(dev))
+    at = net_atol([v.grad for v in lv.values()])
+    for k, v in lv.items():
+        close_grad(G.store.g[k], v.grad, 1e-2, "grad " + k, at)
+    for pre in ("B1.cbn1", "B3.cbn2", "bn"):
+        st = stats[pre]
+        n = st["count"]
+        close(G.store.p[pre + ".mm"], 0.99 * P[pre + ".mm"] + 0.01 * st["mean"], 1e-4, "moving mean " + pre)
+        close(G.store.p[pre + ".mv"], 0.99 * P[pre + ".mv"] + 0.01 * st["var"] * n / (n - 1), 1e-4, "moving variance " + pre)

@@ -80,7 +80,8 @@ int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, fl
  *      sg_conv2d_fwd_bf16v2 / sg_conv2d_bwd_data_bf16v2: contracts of sg_conv2d_fwd / sg_conv2d_bwd_data
  *      (resnet_ops.py:65,98,103,109) with the activation operand given as a bf16 NHWC tensor (x16 / dy16), the filter as the
  *      packed copy of sg_pack_filter_bf16, an fp32 result and, when y16 / dx16 is non-null, a bf16 copy of the result
- *      for the next launch; mask16 (nullable) may replace the fp32 ReLU mask by its bf16 copy.  SG_ERR_UNSUPPORTED unless
+ *      for the next launch (the forward entry points accept y == NULL with y16 != NULL: an operand-only result, no fp32
+ *      tensor is written; not with SG_ACCUM); mask16 (nullable) may replace the fp32 ReLU mask by its bf16 copy.  SG_ERR_UNSUPPORTED unless
  *      reduction channels % 64 == 0 and output channels % 64 == 0:
  *      the caller then uses sg_conv2d_fwd_bf16 / sg_conv2d_bwd_data_bf16 on the fp32 tensor. ----------------------- */
 int sg_cvt_bf16(const float* x, void* out, long n, int relu, const float* rowscale, long rowlen, void* stream);
@@ -120,6 +121,10 @@ int sg_conv2d_transpose_bwd_weight_bf16v2(const void* x16, const void* dy16, flo
  *      (the amax of the result for the NEXT fp8 launch, taken in the epilogue). ------------------------------------ */
 int sg_amax_f32(const float* x, long n, float* amax, void* stream);
 int sg_cvt_fp8(const float* x, void* out, long n, int relu, const float* amax, void* stream);
+/* the same conversion from a bf16 tensor: the fp8 operand of a conv whose input is an OPERAND-ONLY result of the previous conv
+ * (sg_conv2d_fwd_bf16v2 / _fp8 with y == NULL and y16 != NULL: conv1 -> conv2 of a ResNetBlockDown, resnet_ops.py:97-104 -- the
+ * activation between two chained convolutions exists as bf16 only in configs c3 / c5).  n % 8 == 0. */
+int sg_cvt_fp8_bf16(const void* x16, void* out, long n, int relu, const float* amax, void* stream);
 int sg_pack_filter_fp8(const float* w, void* out, const float* amax, int taps, int K, int N, int transpose, void* stream);
 int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias, const float* bias2,
                       float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_y,

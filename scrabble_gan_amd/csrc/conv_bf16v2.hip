@@ -677,18 +677,18 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
       }
       if (accum) { v.x += prev[it].x; v.y += prev[it].y; v.z += prev[it].z; v.w += prev[it].w; }
       if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+      bf16x4v h;
+      if (p.out16) { h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w; }
       if (p.amax_out) {
-        const float a4 = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        // (operand-only results -- no fp32 tensor: the next launch reads the bf16 values, so THEIR amax is recorded)
+        const float4 q = p.out ? v : make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        const float a4 = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
         amx = fmaxf(amx, a4);
         if (p.amax_rowscale) amx_s = fmaxf(amx_s, a4 * fabsf(p.amax_rowscale[(m0 + wm * (TM * 32) + i * 32 + 4 * it + rsub) / HW]));
       }
-      *reinterpret_cast<float4*>(p.out + idx[it]) = v;
-      if (p.out16) {
-        typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-        bf16x4v h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4v*>(p.out16 + idx[it]) = h;
-      }
+      if (p.out) *reinterpret_cast<float4*>(p.out + idx[it]) = v;
+      if (p.out16) *reinterpret_cast<bf16x4v*>(p.out16 + idx[it]) = h;
     }
   }
   if (p.amax_out) {        // (wave-uniform; non-negative floats order like their bit patterns)
@@ -735,7 +735,7 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   // one workgroup per CU: a launch of T equal tiles takes ceil(T / 256) tile-times; the tiles beyond the last multiple of
   // 256 (all of them when T < 512) are cut along the reduction and summed with float atomics (model of launch_cfg in
   // conv_igemm.hip at OCC = 1)
-  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT));
+  const bool can_split = a.out && !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT));   // (partial tiles meet in the fp32 result)
   constexpr int CUS = 256;
   int full = tiles, nsplit = 1;
   if (can_split && g2_split_override != 1 && KT_all >= 8) {
@@ -809,7 +809,7 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
   // rules the float-atomic tail split out) and a narrower tile fills the 256 CUs' rounds better.  Relative tile times:
   // the bf16 loop is bound by the L2 -> LDS feed ((256 + BN) x 128 bytes per tile), the fp32 loop by the matrix pipe.
   const long m_tiles = sg_cdiv((long)a.Bn * a.Hg * a.Wg, SG2_BM);
-  const bool can_split = !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT)) && a.ntaps * (a.Ca / (128 / es)) >= 8;
+  const bool can_split = a.out && !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT)) && a.ntaps * (a.Ca / (128 / es)) >= 8;
   int bn = 0;
   double best = 1e30;
   for (int c = 256; c >= 64; c >>= 1) {
@@ -859,7 +859,7 @@ static int finish_twin(const SgIgemm2Args& a, long rows_done, hipStream_t s) {
 extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const float* bias, const float* bias2, float* y, void* y16,
                                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, float* amax_y,
                                     void* stream) {
-  if (!x16 || !wp_fwd || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (!x16 || !wp_fwd || (!y && !y16) || (!y && (flags & SG_ACCUM)) || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;      // (y null: operand-only result, y16)
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;
   SgIgemm2Args a{};
@@ -1409,6 +1409,29 @@ extern "C" int sg_cvt_fp8(const float* x, void* out, long n, int relu, const flo
   return sg_launch_status();
 }
 
+// the same conversion from a bf16 tensor (an operand-only conv result): out = e4m3(relu?(float(x16)) * 448 / amax[0]); n % 8 == 0
+__global__ __launch_bounds__(256) void k_cvt_fp8_bf16(const bf16x8* __restrict__ x, uint2* __restrict__ out, long n8, int relu, const float* amax) {
+  const float s = sg8_scale(amax);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (long)gridDim.x * blockDim.x) {
+    const bf16x8 h = x[e];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = (float)h[j];
+      if (relu) v[j] = fmaxf(v[j], 0.f);
+      v[j] *= s;
+    }
+    out[e] = make_uint2(sg8_pack4(v[0], v[1], v[2], v[3]), sg8_pack4(v[4], v[5], v[6], v[7]));
+  }
+}
+
+extern "C" int sg_cvt_fp8_bf16(const void* x16, void* out, long n, int relu, const float* amax, void* stream) {
+  if (!x16 || !out || !amax || n < 0 || (n & 7)) return SG_ERR_ARG;
+  if (n == 0) return SG_OK;
+  SG_KERNEL(k_cvt_fp8_bf16, dim3(sg_grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x16, (uint2*)out, n / 8, relu, amax);
+  return sg_launch_status();
+}
+
 // filter packing: fp32 [taps][K][N] (transpose = 1) or [taps][N][K] (transpose = 0) -> fp8 [taps][N][K], scaled by 448 / amax
 __global__ __launch_bounds__(256) void k_pack_filter_fp8(const float* w, unsigned char* out, const float* amax, int K, int N, int transpose) {
   __shared__ float tile[32][33];
@@ -1448,7 +1471,7 @@ extern "C" int sg_pack_filter_fp8(const float* w, void* out, const float* amax, 
 extern "C" int sg_conv2d_fwd_fp8(const void* x8, const float* amax_x, const void* wp8, const float* amax_w, const float* bias,
                                  const float* bias2, float* y, void* y16, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                                  int pad_same, int flags, float* amax_y, void* stream) {
-  if (!x8 || !wp8 || !amax_x || !amax_w || !y || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
+  if (!x8 || !wp8 || !amax_x || !amax_w || (!y && !y16) || (!y && (flags & SG_ACCUM)) || kh * kw > SG_MAX_TAPS) return SG_ERR_ARG;
   if (flags & SG_RELU_IN) return SG_ERR_UNSUPPORTED;           // fold the ReLU into sg_cvt_fp8
   const int ph = pad_same ? kh / 2 : 0, pw = pad_same ? kw / 2 : 0;
   const int Ho = pad_same ? H : H - kh + 1, Wo = pad_same ? W : W - kw + 1;

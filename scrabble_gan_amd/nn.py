@@ -208,7 +208,8 @@ def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
     shortcut; they are the least efficient MFMA launches of the step: 64 / 512 reduction terms).  POOL_FIRST_SHORTCUT = False
     keeps the reference's order; both are parity-tested against the oracle (which pools last)."""
     p = S.p
-    c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True, want16=True)          # :97-99
+    # (c1 feeds only conv2 and conv2's backward launches: in bf16 / fp8 modes it may exist as a bf16 operand copy alone)
+    c1 = ops.conv2d_fwd(x, p[pre + ".conv1.w"], p[pre + ".conv1.b"], relu_in=True, want16="only")        # :97-99
     xp = None
     if is_last:
         out = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])                     # :109-111

@@ -241,3 +241,53 @@ def test_fp8_producer_amax_is_the_amax_of_the_result(dev, gen, fp8_mode, B):
     o5r, a5r, csr = ops.grad_operand_fp8(dx, sc, True)
     o4r, a4r = ops.fp8_of(dx)
     assert a5.item() == a5r.item() and a4.item() == a4r.item() and torch.equal(o5, o5r) and torch.equal(o4, o4r)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_operand_only_conv_result(dev, gen, mode):
+    """conv1 -> conv2 of a ResNetBlockDown (resnet_ops.py:97-104) in configs c3 / c5: ops.conv2d_fwd(want16="only") writes the bf16
+    operand copy of c1 ALONE; the fp32 tensor it returns is a never-written handle (poisoned with NaN in the tests).  The copy must be
+    bit-identical to the twin of the ordinary launch; conv2, the ReLU mask of its data-grad and its weight-grad must give the SAME
+    results from the handle as from the real tensor (bf16 mode: bitwise, they read the same bytes); in fp8 mode c1's e4m3 operand is
+    quantised from the bf16 values with the amax the epilogue recorded OF THOSE VALUES (bit-exact against torch.float8_e4m3fn)."""
+    from scrabble_gan_amd import ops
+    try:
+        ops.set_conv_dtype(mode)
+        B, H, W, Cin, C = 64, 16, 80, 64, 512            # B2.conv1 at the shard batch of c5: 640 tiles of 256 x 256
+        x = g32(rnd(gen, B, H, W, Cin), dev)
+        w1 = g32(rnd(gen, 3, 3, Cin, C) / math.sqrt(9 * Cin), dev)
+        b1 = g32(rnd(gen, C), dev)
+        w2 = g32(rnd(gen, 3, 3, C, C) / math.sqrt(9 * C), dev)
+        dy = g32(rnd(gen, B, H, W, C), dev)
+        assert ops.operand_only_ok(B, H, W, C)
+        c_ref = ops.conv2d_fwd(x, w1, b1, relu_in=True, want16=True)
+        t_ref = ops.bf16_of(c_ref).clone()
+        y_ref = ops.conv2d_fwd(c_ref, w2, relu_in=True)
+        d_ref = ops.conv2d_bwd_data(dy, w2, (H, W), mask=c_ref)
+        dw_ref = torch.zeros_like(w2)
+        ops.conv2d_bwd_weight(c_ref, dy, dw_ref, relu_in=True)
+        ops.new_step()
+        c_g = ops.conv2d_fwd(x, w1, b1, relu_in=True, want16="only")
+        assert torch.isnan(c_g).all(), "the fp32 handle of an operand-only result must not be written"
+        t_g = ops.bf16_of(c_g)
+        assert torch.equal(t_g, t_ref)
+        y_g = ops.conv2d_fwd(c_g, w2, relu_in=True)
+        d_g = ops.conv2d_bwd_data(dy, w2, (H, W), mask=c_g)
+        dw_g = torch.zeros_like(w2)
+        ops.conv2d_bwd_weight(c_g[: B // 2], dy[: B // 2].contiguous(), dw_g, relu_in=True)          # (a batch slice of the handle, as the fused passes take)
+        ops.conv2d_bwd_weight(c_g[B // 2:], dy[B // 2:].contiguous(), dw_g, relu_in=True)
+        assert torch.isfinite(y_g).all() and torch.isfinite(d_g).all() and torch.isfinite(dw_g).all()
+        if mode == "bf16":
+            assert torch.equal(y_g, y_ref) and torch.equal(d_g, d_ref)
+            close(dw_g, dw_ref, 1e-5, "dW from the two halves of the handle")
+        else:
+            q, am = ops.fp8_of(c_g, relu=True)
+            tf = t_g.float()
+            assert am.item() == tf.abs().max().item()
+            want = (torch.relu(tf) * (torch.tensor(448.0, device=dev) / tf.abs().max()).float()).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+            assert torch.equal(q & 0x7f, want & 0x7f)
+            close(y_g, y_ref, 2e-2, "conv2 on the e4m3 operand taken from bf16 values vs from fp32 values")
+            assert torch.equal(d_g, d_ref)                       # (the mask is the bf16 twin either way)
+            close(dw_g, dw_ref, 3e-2, "fp8 dW, per-slice amax vs whole-tensor amax")
+    finally:
+        ops.set_conv_dtype("f32")

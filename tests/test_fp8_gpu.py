@@ -260,6 +260,9 @@ def test_operand_only_conv_result(dev, gen, mode):
         w2 = g32(rnd(gen, 3, 3, C, C) / math.sqrt(9 * C), dev)
         dy = g32(rnd(gen, B, H, W, C), dev)
         assert ops.operand_only_ok(B, H, W, C)
+        # reference = the ordinary launches WITHOUT reduction-split tails (an operand-only launch has none: partial tiles meet in
+        # the fp32 result), so that every output element sums the same products in the same order
+        ops.set_deterministic(True)
         c_ref = ops.conv2d_fwd(x, w1, b1, relu_in=True, want16=True)
         t_ref = ops.bf16_of(c_ref).clone()
         y_ref = ops.conv2d_fwd(c_ref, w2, relu_in=True)
@@ -267,6 +270,7 @@ def test_operand_only_conv_result(dev, gen, mode):
         dw_ref = torch.zeros_like(w2)
         ops.conv2d_bwd_weight(c_ref, dy, dw_ref, relu_in=True)
         ops.new_step()
+        ops.set_deterministic(False)
         c_g = ops.conv2d_fwd(x, w1, b1, relu_in=True, want16="only")
         assert torch.isnan(c_g).all(), "the fp32 handle of an operand-only result must not be written"
         t_g = ops.bf16_of(c_g)
@@ -278,7 +282,8 @@ def test_operand_only_conv_result(dev, gen, mode):
         ops.conv2d_bwd_weight(c_g[B // 2:], dy[B // 2:].contiguous(), dw_g, relu_in=True)
         assert torch.isfinite(y_g).all() and torch.isfinite(d_g).all() and torch.isfinite(dw_g).all()
         if mode == "bf16":
-            assert torch.equal(y_g, y_ref) and torch.equal(d_g, d_ref)
+            close(y_g, y_ref, 2e-6, "conv2 (same operand bytes; the default launch splits its tail tiles)")
+            close(d_g, d_ref, 2e-6, "data-grad with the handle as ReLU mask")
             close(dw_g, dw_ref, 1e-5, "dW from the two halves of the handle")
         else:
             q, am = ops.fp8_of(c_g, relu=True)
@@ -287,7 +292,8 @@ def test_operand_only_conv_result(dev, gen, mode):
             want = (torch.relu(tf) * (torch.tensor(448.0, device=dev) / tf.abs().max()).float()).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
             assert torch.equal(q & 0x7f, want & 0x7f)
             close(y_g, y_ref, 2e-2, "conv2 on the e4m3 operand taken from bf16 values vs from fp32 values")
-            assert torch.equal(d_g, d_ref)                       # (the mask is the bf16 twin either way)
+            close(d_g, d_ref, 2e-6, "data-grad with the handle as ReLU mask")       # (the mask is the bf16 twin either way)
             close(dw_g, dw_ref, 3e-2, "fp8 dW, per-slice amax vs whole-tensor amax")
     finally:
+        ops.set_deterministic(False)
         ops.set_conv_dtype("f32")

@@ -765,7 +765,8 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   a.tail_split = nsplit;
   a.n_tiles_total = tiles;
   static bool attr_done = false;
-  constexpr int LDS_BYTES = 2 * SG2_TILE + 2 * BN * 128;
+  static const int lds_pad = getenv("SG2_LDS_PAD") ? atoi(getenv("SG2_LDS_PAD")) : 0;      // (occupancy probe: extra bytes requested, never touched)
+  const int LDS_BYTES = 2 * SG2_TILE + 2 * BN * 128 + lds_pad;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();

@@ -178,13 +178,19 @@ constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A s
 // RELU: max(a, 0) on the A fragments in registers (SG_RELU_IN); compiled out otherwise -- a VALU instruction in front of an
 // MFMA pair is NOT free on the fp32 stream (tools/mfma_peak.hip: 154 -> 141 TFLOP/s with two per pair), so launches without
 // the flag (every data-grad, convs behind a fused BN+ReLU) run a loop without any.
-template <int BN, int ES, bool RELU>
-__global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
+// BMT = rows of the A tile: 256 (8 waves, one workgroup per CU) or 128 with BN = 128 (round 3: 4 waves as 2 x 2 of 64 x 64 wave
+// tiles, 64 KB of LDS -> TWO workgroups per CU: the HBM-bound epilogue of one overlaps the k-loop of the other; the 64-filter
+// configuration, which sits at two per CU already, loses 35-45 % when forced down to one: profiles/r03_probe_occupancy64.txt)
+template <int BN, int ES, bool RELU, int BMT = 256>
+__global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int BM = SG2_BM, BK = 128 / ES;            // channels per k-tile
-  constexpr int WN = BN / 64, WM = 8 / WN;              // waves along n / m
+  constexpr int BM = BMT, BK = 128 / ES;               // channels per k-tile
+  constexpr int NW = BM == 256 ? 8 : 4;                 // waves per workgroup
+  constexpr int ATILE = BM * 128;                       // bytes of an A stage
+  constexpr int WN = BN / 64, WM = NW / WN;             // waves along n / m
   constexpr int TM = BM / WM / 32, TN = 2;              // 32 x 32 MFMA tiles per wave
-  constexpr int BQ = BN / 64;                           // B-tile DMA instructions per thread
+  constexpr int BQ = BN / (8 * NW);                     // B-tile DMA instructions per thread
+  static_assert(BM == 256 || (BM == 128 && BN == 128), "tile configurations");
   constexpr int BTILE = BN * 128;                       // bytes of the B tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   unsigned a_off[4], a_msk[4], b_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (8 * i + wave) * 8 + lrow;
+    const int r = (NW * i + wave) * 8 + lrow;
     const int chunk = lslot ^ ((r >> 1) & 7);
     const int m = m0 + r;
     const bool ok = m < M;
@@ -280,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     const unsigned char* src_a = reinterpret_cast<const unsigned char*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
     const unsigned long long pb = cur_live ? w_base64 + (unsigned long long)(b_off[q] + (unsigned)cur_w) : z_base64;
     const unsigned char* src_b = reinterpret_cast<const unsigned char*>((uintptr_t)pb);
-    unsigned char* dst_a = smem + st * SG2_TILE + (8 * q + wave) * 1024;
-    unsigned char* dst_b = smem + 2 * SG2_TILE + st * BTILE + (8 * q + wave) * 1024;
+    unsigned char* dst_a = smem + st * ATILE + (NW * q + wave) * 1024;
+    unsigned char* dst_b = smem + 2 * ATILE + st * BTILE + (NW * q + wave) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a, (__attribute__((address_space(3))) void*)dst_a, 16, 0, 0);
     if (q < BQ)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_b, (__attribute__((address_space(3))) void*)dst_b, 16, 0, 0);
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   for (int s = 0; s < 4; ++s) {
     const unsigned ko = 16u * (unsigned)((2 * s + khalf) ^ swz);
     a_addr[s] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
-    b_addr[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+    b_addr[s] = lds0 + (unsigned)(2 * ATILE + (wn * 64 + frow) * 128) + ko;
   }
   const s16x8 rfloor8 = {0, 0, 0, 0, 0, 0, 0, 0};      // (bf16 compares like a sign-magnitude integer: max as int16 against +0)
 
@@ -319,10 +325,10 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   // (macros, not lambdas: the stage / step / slot must reach the asm as literal constants)
 #define SG2_READ_FRAGS(st, s, slot)                                                   \
   do {                                                                                \
-    SG2_DSR(af[slot][0], a_addr[s], (st) * SG2_TILE + 0 * 4096);                      \
-    if constexpr (TM > 1) SG2_DSR(af[slot][1], a_addr[s], (st) * SG2_TILE + 1 * 4096); \
-    if constexpr (TM > 2) SG2_DSR(af[slot][2], a_addr[s], (st) * SG2_TILE + 2 * 4096); \
-    if constexpr (TM > 2) SG2_DSR(af[slot][3], a_addr[s], (st) * SG2_TILE + 3 * 4096); \
+    SG2_DSR(af[slot][0], a_addr[s], (st) * ATILE + 0 * 4096);                      \
+    if constexpr (TM > 1) SG2_DSR(af[slot][1], a_addr[s], (st) * ATILE + 1 * 4096); \
+    if constexpr (TM > 2) SG2_DSR(af[slot][2], a_addr[s], (st) * ATILE + 2 * 4096); \
+    if constexpr (TM > 2) SG2_DSR(af[slot][3], a_addr[s], (st) * ATILE + 3 * 4096); \
     SG2_DSR(bfr[slot][0], b_addr[s], (st) * BTILE + 0 * 4096);                        \
     SG2_DSR(bfr[slot][1], b_addr[s], (st) * BTILE + 1 * 4096);                        \
   } while (0)
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
     for (int e = 0; e < 2; ++e) {
       const unsigned ko = 16u * (unsigned)((4 * s + 2 * khalf + e) ^ swz);
       a8[s][e] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
-      b8[s][e] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+      b8[s][e] = lds0 + (unsigned)(2 * ATILE + (wn * 64 + frow) * 128) + ko;
     }
   // ONE fragment set (48 registers; a second one does not fit beside the 128 accumulators): the reads of the next step are
   // issued right behind the MFMAs of the current one (an MFMA takes its operands at issue), the partner wave of the SIMD
@@ -405,14 +411,14 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   v4i afl[1][4], afh[1][4], bfl[1][2], bfh[1][2];    // [slot][group], low / high 16 bytes of a fragment
 #define SG8_READ_FRAGS(st, s, slot)                                                          \
   do {                                                                                       \
-    SG2_DSR(afl[slot][0], a8[s][0], (st) * SG2_TILE + 0 * 4096);                             \
-    SG2_DSR(afh[slot][0], a8[s][1], (st) * SG2_TILE + 0 * 4096);                             \
-    if constexpr (TM > 1) SG2_DSR(afl[slot][1], a8[s][0], (st) * SG2_TILE + 1 * 4096);       \
-    if constexpr (TM > 1) SG2_DSR(afh[slot][1], a8[s][1], (st) * SG2_TILE + 1 * 4096);       \
-    if constexpr (TM > 2) SG2_DSR(afl[slot][2], a8[s][0], (st) * SG2_TILE + 2 * 4096);       \
-    if constexpr (TM > 2) SG2_DSR(afh[slot][2], a8[s][1], (st) * SG2_TILE + 2 * 4096);       \
-    if constexpr (TM > 2) SG2_DSR(afl[slot][3], a8[s][0], (st) * SG2_TILE + 3 * 4096);       \
-    if constexpr (TM > 2) SG2_DSR(afh[slot][3], a8[s][1], (st) * SG2_TILE + 3 * 4096);       \
+    SG2_DSR(afl[slot][0], a8[s][0], (st) * ATILE + 0 * 4096);                             \
+    SG2_DSR(afh[slot][0], a8[s][1], (st) * ATILE + 0 * 4096);                             \
+    if constexpr (TM > 1) SG2_DSR(afl[slot][1], a8[s][0], (st) * ATILE + 1 * 4096);       \
+    if constexpr (TM > 1) SG2_DSR(afh[slot][1], a8[s][1], (st) * ATILE + 1 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afl[slot][2], a8[s][0], (st) * ATILE + 2 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afh[slot][2], a8[s][1], (st) * ATILE + 2 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afl[slot][3], a8[s][0], (st) * ATILE + 3 * 4096);       \
+    if constexpr (TM > 2) SG2_DSR(afh[slot][3], a8[s][1], (st) * ATILE + 3 * 4096);       \
     SG2_DSR(bfl[slot][0], b8[s][0], (st) * BTILE + 0 * 4096);                                \
     SG2_DSR(bfh[slot][0], b8[s][1], (st) * BTILE + 0 * 4096);                                \
     SG2_DSR(bfl[slot][1], b8[s][0], (st) * BTILE + 1 * 4096);                                \
@@ -462,16 +468,16 @@ __global__ __launch_bounds__(512, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2A
   for (int s = 0; s < 8; ++s) {
     const unsigned ko = 16u * (unsigned)(s ^ swz) + 8u * (unsigned)khalf;
     a4[s] = lds0 + (unsigned)((wm * (TM * 32) + frow) * 128) + ko;
-    b4[s] = lds0 + (unsigned)(2 * SG2_TILE + (wn * 64 + frow) * 128) + ko;
+    b4[s] = lds0 + (unsigned)(2 * ATILE + (wn * 64 + frow) * 128) + ko;
   }
   v2f af4[2][4], bf4[2][2];
 #define SG4_DSR(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define SG4_READ_FRAGS(st, s, slot)                                                          \
   do {                                                                                       \
-    SG4_DSR(af4[slot][0], a4[s], (st) * SG2_TILE + 0 * 4096);                                \
-    if constexpr (TM > 1) SG4_DSR(af4[slot][1], a4[s], (st) * SG2_TILE + 1 * 4096);          \
-    if constexpr (TM > 2) SG4_DSR(af4[slot][2], a4[s], (st) * SG2_TILE + 2 * 4096);          \
-    if constexpr (TM > 2) SG4_DSR(af4[slot][3], a4[s], (st) * SG2_TILE + 3 * 4096);          \
+    SG4_DSR(af4[slot][0], a4[s], (st) * ATILE + 0 * 4096);                                \
+    if constexpr (TM > 1) SG4_DSR(af4[slot][1], a4[s], (st) * ATILE + 1 * 4096);          \
+    if constexpr (TM > 2) SG4_DSR(af4[slot][2], a4[s], (st) * ATILE + 2 * 4096);          \
+    if constexpr (TM > 2) SG4_DSR(af4[slot][3], a4[s], (st) * ATILE + 3 * 4096);          \
     SG4_DSR(bf4[slot][0], b4[s], (st) * BTILE + 0 * 4096);                                   \
     SG4_DSR(bf4[slot][1], b4[s], (st) * BTILE + 1 * 4096);                                   \
   } while (0)
@@ -725,18 +731,18 @@ __global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, 
 static int g2_split_override = -1;
 extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
 
-template <int BN, int ES, bool RELU>
+template <int BN, int ES, bool RELU, int BMT = 256>
 static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int n_tiles = a.N / BN;
-  const int tiles = sg_cdiv(M, SG2_BM) * n_tiles;
+  const int tiles = sg_cdiv(M, BMT) * n_tiles;
   if (tiles <= 0) return SG_OK;
   const int KT_all = a.ntaps * (a.Ca / (128 / ES));
   // one workgroup per CU: a launch of T equal tiles takes ceil(T / 256) tile-times; the tiles beyond the last multiple of
   // 256 (all of them when T < 512) are cut along the reduction and summed with float atomics (model of launch_cfg in
   // conv_igemm.hip at OCC = 1)
   const bool can_split = a.out && !(a.flags & SG_RELU_OUT) && ((a.flags & SG_ACCUM) || (a.flags & SG2_IDENT_OUT));   // (partial tiles meet in the fp32 result)
-  constexpr int CUS = 256;
+  constexpr int CUS = BMT == 256 ? 256 : 512;          // workgroup slots of the chip for this configuration
   int full = tiles, nsplit = 1;
   if (can_split && g2_split_override != 1 && KT_all >= 8) {
     const int rem = tiles % CUS;
@@ -757,7 +763,7 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
       if (best > 1) { full = full_c; nsplit = best; }
     }
   }
-  const long row0 = nsplit > 1 ? (long)(full / n_tiles) * SG2_BM : M;
+  const long row0 = nsplit > 1 ? (long)(full / n_tiles) * BMT : M;
   if (nsplit > 1 && !(a.flags & SG_ACCUM)) {
     if (hipMemsetAsync(a.out + (size_t)row0 * a.N, 0, sizeof(float) * (size_t)(M - row0) * a.N, s) != hipSuccess) return SG_ERR_LAUNCH;
   }
@@ -766,15 +772,15 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   a.n_tiles_total = tiles;
   static bool attr_done = false;
   static const int lds_pad = getenv("SG2_LDS_PAD") ? atoi(getenv("SG2_LDS_PAD")) : 0;      // (occupancy probe: extra bytes requested, never touched)
-  const int LDS_BYTES = 2 * SG2_TILE + 2 * BN * 128 + lds_pad;
+  const int LDS_BYTES = 2 * BMT * 128 + 2 * BN * 128 + lds_pad;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  SG_KERNEL((sg_igemm_bf16v2_kernel<BN, ES, RELU>), dim3(full + (tiles - full) * nsplit), dim3(512), LDS_BYTES, s, a);
+  SG_KERNEL((sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT>), dim3(full + (tiles - full) * nsplit), dim3(BMT == 256 ? 512 : 256), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   if (a.amax_out && nsplit > 1) {
     // the split tiles' values are final only now: their amax comes from a sweep over those rows (identity layouts: the rows
@@ -788,10 +794,17 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   return sg_launch_status();
 }
 
-template <int BN, int ES>
+template <int BN, int ES, int BMT = 256>
 static int sg2_launch_bn(const SgIgemm2Args& a, hipStream_t s, long* twin_rows_done) {
-  if constexpr (ES == 1) return sg2_launch_bn_r<BN, ES, false>(a, s, twin_rows_done);     // (fp8: the ReLU is applied by the fp8 convert)
-  else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false>(a, s, twin_rows_done);
+  if constexpr (ES == 1) return sg2_launch_bn_r<BN, ES, false, BMT>(a, s, twin_rows_done);     // (fp8: the ReLU is applied by the fp8 convert)
+  else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true, BMT>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false, BMT>(a, s, twin_rows_done);
+}
+
+// The 128 x 128 configuration pays twice the L2 -> LDS bytes per FLOP and a third more LDS reads per MFMA; it wins where the epilogue
+// (HBM-bound, ~ output bytes) is a large share of the launch: short reductions.  (Rule from tools/bench_conv.py per-layer timings.)
+static bool sg2_prefer_128(const SgIgemm2Args& a, long m_tiles) {
+  const long k_total = (long)a.ntaps * a.Ca;
+  return k_total <= 4608 && m_tiles * (a.N / 128) >= 512;
 }
 
 // -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
@@ -834,6 +847,9 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);
     return sg2_launch_bn<64, 4>(a, s, twin_rows_done);
   }
+  // bf16: the 128 x 128 / two-workgroups-per-CU configuration (SG2_TILE128: 0 never, 2 whenever N % 128 == 0, 1 = the rule below)
+  static const int t128 = getenv("SG2_TILE128") ? atoi(getenv("SG2_TILE128")) : 1;
+  if (a.N % 128 == 0 && bn >= 128 && (t128 == 2 || (t128 == 1 && sg2_prefer_128(a, m_tiles)))) return sg2_launch_bn<128, 2, 128>(a, s, twin_rows_done);
   if (bn == 256) return sg2_launch_bn<256, 2>(a, s, twin_rows_done);
   if (bn == 128) return sg2_launch_bn<128, 2>(a, s, twin_rows_done);
   return sg2_launch_bn<64, 2>(a, s, twin_rows_done);

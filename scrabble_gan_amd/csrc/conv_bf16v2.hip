@@ -800,11 +800,12 @@ static int sg2_launch_bn(const SgIgemm2Args& a, hipStream_t s, long* twin_rows_d
   else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true, BMT>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false, BMT>(a, s, twin_rows_done);
 }
 
-// The 128 x 128 configuration pays twice the L2 -> LDS bytes per FLOP and a third more LDS reads per MFMA; it wins where the epilogue
-// (HBM-bound, ~ output bytes) is a large share of the launch: short reductions.  (Rule from tools/bench_conv.py per-layer timings.)
+// SG2_TILE128 / sg_debug_set_tile128: 0 = never (default), 1 = the rule below, 2 = whenever the filter count is a multiple of 128
+static int g2_tile128 = getenv("SG2_TILE128") ? atoi(getenv("SG2_TILE128")) : 0;
+extern "C" void sg_debug_set_tile128(int mode) { g2_tile128 = mode; }
+// where the 128 x 128 configuration measured ahead: 1x1 convolutions over >= 1024 channels on few pixels (the epilogue is most of the launch)
 static bool sg2_prefer_128(const SgIgemm2Args& a, long m_tiles) {
-  const long k_total = (long)a.ntaps * a.Ca;
-  return k_total <= 4608 && m_tiles * (a.N / 128) >= 512;
+  return a.ntaps == 1 && a.Ca >= 1024 && m_tiles <= 1024;
 }
 
 // -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
@@ -847,9 +848,11 @@ static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long*
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);
     return sg2_launch_bn<64, 4>(a, s, twin_rows_done);
   }
-  // bf16: the 128 x 128 / two-workgroups-per-CU configuration (SG2_TILE128: 0 never, 2 whenever N % 128 == 0, 1 = the rule below)
-  static const int t128 = getenv("SG2_TILE128") ? atoi(getenv("SG2_TILE128")) : 1;
-  if (a.N % 128 == 0 && bn >= 128 && (t128 == 2 || (t128 == 1 && sg2_prefer_128(a, m_tiles)))) return sg2_launch_bn<128, 2, 128>(a, s, twin_rows_done);
+  // bf16: the 128 x 128 / two-workgroups-per-CU configuration.  MEASURED SLOWER than the wide tiles on every layer of the step but
+  // the 4x20 1x1 shortcut (profiles/r03_probe_tile128.txt: 512 -> 512 16x80 forward 1 116 -> 892 TF/s, data-grad 976 -> 863): twice the
+  // L2 -> LDS bytes per FLOP and a third more LDS reads per MFMA cost more than the overlapped epilogue returns.  Kept (parity-green
+  // when forced: sg_debug_set_tile128(2) / SG2_TILE128=2) as the starting point for a 256 x 128 two-workgroup variant; off by default.
+  if (a.N % 128 == 0 && bn >= 128 && (g2_tile128 == 2 || (g2_tile128 == 1 && sg2_prefer_128(a, m_tiles)))) return sg2_launch_bn<128, 2, 128>(a, s, twin_rows_done);
   if (bn == 256) return sg2_launch_bn<256, 2>(a, s, twin_rows_done);
   if (bn == 128) return sg2_launch_bn<128, 2>(a, s, twin_rows_done);
   return sg2_launch_bn<64, 2>(a, s, twin_rows_done);

@@ -274,3 +274,35 @@ def test_conv2d_transpose_weight_grad_bf16(dev, gen, bf16_mode, B, H, W, Cin, Co
     dw = torch.full((k, k, Cout, Cin), 0.5, device=dev)
     ops.conv2d_transpose_bwd_weight(g32(x, dev), g32(dy, dev), dw, stride=stride)
     close(dw - 0.5, w.grad, 1e-4, "convT weight-grad vs bf16-rounded-operand oracle")
+
+
+def test_tile128_configuration_when_forced(dev):
+    """The 128 x 128 / two-workgroups-per-CU configuration of the DMA-fed kernel (off by default: measured slower,
+    profiles/r03_probe_tile128.txt) stays parity-green: forced through sg_debug_set_tile128(2), forward (ReLU, bias, split tails
+    and full rounds) and data-grad (mask, accumulate) against the oracle on bf16-rounded operands, 5e-5."""
+    import math
+    from scrabble_gan_amd import ops
+    from scrabble_gan_amd._lib import lib
+    g = torch.Generator().manual_seed(128)
+    try:
+        ops.set_conv_dtype("bf16")
+        lib().sg_debug_set_tile128(2)
+        for (B, H, W, Cin, Cout, k) in ((3, 8, 40, 256, 256, 3), (40, 4, 20, 128, 384, 1), (5, 7, 5, 512, 128, 3)):
+            x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64)
+            w = torch.randn(k, k, Cin, Cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * Cin)
+            b = torch.randn(Cout, generator=g, dtype=torch.float64)
+            dy = torch.randn(B, H, W, Cout, generator=g, dtype=torch.float64)
+            r16 = lambda t: t.float().to(torch.bfloat16).to(torch.float64)
+            xg, wg, bg, dyg = (t.float().to(dev).contiguous() for t in (x, w, b, dy))
+            y = ops.conv2d_fwd(xg, wg, bg, relu_in=True)
+            ref = O.conv2d(r16(torch.relu(x)), r16(w), b)
+            assert (y.double().cpu() - ref).abs().max().item() <= 5e-5 * ref.abs().max().item(), (B, Cin, Cout, "fwd")
+            base = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64)
+            dx = ops.conv2d_bwd_data(dyg, wg, (H, W), mask=xg, out=base.float().to(dev), accum=True)
+            xr = x.clone().requires_grad_(True)
+            O.conv2d(xr, r16(w), None).backward(r16(dy))
+            refd = xr.grad * (x > 0) + base.float().double()
+            assert (dx.double().cpu() - refd).abs().max().item() <= 5e-5 * refd.abs().max().item(), (B, Cin, Cout, "dgrad")
+    finally:
+        lib().sg_debug_set_tile128(0)
+        ops.set_conv_dtype("f32")

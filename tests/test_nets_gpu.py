@@ -386,7 +386,9 @@ def _problem(L_f):
     return _PROBLEMS[L_f]
 
 
-@pytest.mark.parametrize("loss_name,balance,L_f", [("hinge", False, 3), ("not_saturating", True, 3), ("hinge", True, 2)])
+# (hinge without balancing on separate passes -- the third mode -- is tests/test_configs_gpu.py::test_c4_bucketed_step_against_oracle: the
+#  same check on the harder bucketed-width problem; round 3 dropped its twin here to keep the GPU suite at ~10 minutes)
+@pytest.mark.parametrize("loss_name,balance,L_f", [("not_saturating", True, 3), ("hinge", True, 2)])
 def test_train_step(setup, dev, loss_name, balance, L_f, request):
     """One whole train_step (B = 8) against the fp64 oracle, with a CALIBRATED tolerance instead of a guessed one.
 

@@ -145,8 +145,9 @@ def committed_traffic(kernel, conv_dtype, per_gpu_batch):
         return None, None
     tj = json.load(open(files[-1]))
     rel = "profiles/" + os.path.basename(files[-1])
-    return tj["traffic_bytes_per_launch"], "%s @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % (
-        rel, _git_commit_of(rel))
+    # (the file records the commit its PMC passes ran on; git itself is not available on a box that received a snapshot)
+    stamp = tj.get("source_commit") or _git_commit_of(rel)
+    return tj["traffic_bytes_per_launch"], "%s @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % (rel, stamp)
 
 
 def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev, world, bucketed=False, sync_every_step=False,

@@ -173,10 +173,19 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     il_f, il_r = ctc_input_length(L_f), ctc_input_length(L_r)
     plain = all(getattr(m, "supports_fused_passes", True) for m in (D, S))     # (make_my_discriminator: separate passes and sweeps)
     fuse = fuse_passes and plain and x_f.shape == images.shape
+    use_ns = False
     if fuse:
-        (d_f, d_r), ctx_D, _ = D.forward_multi([x_f, images], [nl.get("D.fake"), nl.get("D.real")])
         fuse_style = style.shape == x_f.shape
-        if fuse_style:
+        # small per-GPU batches (the data-parallel shards): S's passes on a second stream beside D's and R's (ops.net_stream)
+        use_ns = fuse_style and ops.net_stream_enabled(3 * B)
+        if use_ns:
+            nls = [nl.get("S.fake"), nl.get("S.style"), nl.get("S.real")]
+            with ops.net_stream(x_f, style, images, *[t for d in nls if d is not None for t in d.values()]) as ns_f:
+                (s_f, s_my, s_r), ctx_S, _ = S.forward_multi([x_f, style, images], nls)
+        (d_f, d_r), ctx_D, _ = D.forward_multi([x_f, images], [nl.get("D.fake"), nl.get("D.real")])
+        if use_ns:
+            pass
+        elif fuse_style:
             (s_f, s_my, s_r), ctx_S, _ = S.forward_multi([x_f, style, images], [nl.get("S.fake"), nl.get("S.style"), nl.get("S.real")])
         else:
             (s_f, s_r), ctx_S, _ = S.forward_multi([x_f, images], [nl.get("S.fake"), nl.get("S.real")])
@@ -196,6 +205,8 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         s_r, _ = S.forward(images, nl.get("S.real"))
         r_r, ctx_rr = R.forward(images, labels_t, il_r, L_r, training=True)
 
+    if use_ns:
+        ns_f.join(s_f, s_my, s_r)
     if DEBUG_KEEP is not None:                                      # (tests: the recognizer's ReLU / max-pool decisions)
         DEBUG_KEEP["R_f"] = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
         DEBUG_KEEP["R_r"] = R.slice_ctx(ctx_R, B, 2 * B) if (fuse and fuse_r) else ctx_rr
@@ -224,6 +235,13 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         m.store.zero_grad()
     discriminator.trainable = True
     dx_d = dx_s = None
+    ns_b = None
+    if use_ns and share:               # S's sweep first, on the network stream; D's and R's follow on the launch stream
+        style_promoter.trainable = True
+        with ops.net_stream(shS, gS_my, ones_b) as ns_b:
+            dxs_all = S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([shS[0], gS_my]), want_dx=True, want_dw=True,
+                                 wscale=torch.cat([shS[1], ones_b]))
+            dx_s = ops.rowscale(dxs_all[:B], shS[2])
     if fuse and share:
         dx_all = D.backward(ctx_D, torch.cat([shD[0], gD_r]), want_dx=True, want_dw=True, wscale=torch.cat([shD[1], ones_b]))
         dx_d = ops.rowscale(dx_all[:B], shD[2])
@@ -244,7 +262,9 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         R.backward(ctx_rr, ones, want_dx=False, want_dw=True)
     pending.append(red.all_reduce_sum_async(R.store.grad))
     style_promoter.trainable = True
-    if fuse and fuse_style:
+    if ns_b is not None:
+        ns_b.join(dx_s)                # (S's gradients and image gradient are complete from here on, on the launch stream)
+    elif fuse and fuse_style:
         if share:
             dxs_all = S.backward(S.slice_ctx(ctx_S, 0, 2 * B), torch.cat([shS[0], gS_my]), want_dx=True, want_dw=True,
                                  wscale=torch.cat([shS[1], ones_b]))

@@ -127,9 +127,7 @@ def _stream() -> int:
 # (-1 %: the grids fill many rounds of the chip, two resident kernels only compete for L2).  SG_SIDE_WGRAD=0 disables it.
 SIDE_WGRAD = _os.environ.get("SG_SIDE_WGRAD", "1") == "1"
 SIDE_MAX_BATCH = int(_os.environ.get("SG_SIDE_MAX_BATCH", "96"))
-_SIDE = {"stream": None, "dirty": False}
-
-
+_SIDE = {}             # raw handle of the stream that is "main" for a sweep -> {"stream": its side stream, "dirty": bool}
 CAPTURING = False      # graph_step.GraphedStep sets this while a step is captured into a HIP graph (single stream)
 
 
@@ -137,10 +135,19 @@ def side_enabled() -> bool:
     return SIDE_WGRAD and PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32" and not CAPTURING
 
 
+def _side_of_current():
+    key = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    e = _SIDE.get(key)
+    if e is None:
+        e = {"stream": torch.cuda.Stream(), "dirty": False}
+        _SIDE[key] = e
+    return e
+
+
 class side_stream:
-    """with ops.side_stream(t1, t2, ...): the launches inside run on the side stream, after everything queued so far on the
-    main stream (in particular the producers of t1, t2, ... -- tensors the side launches read: their memory is not handed out
-    again before the side stream is done with them).  A no-op context when side_enabled() is False."""
+    """with ops.side_stream(t1, t2, ...): the launches inside run on the side stream OF THE CURRENT STREAM, after everything queued
+    so far on the current stream (in particular the producers of t1, t2, ... -- tensors the side launches read: their memory is
+    not handed out again before the side stream is done with them).  A no-op context when side_enabled() is False."""
 
     def __init__(self, *inputs):
         self.on = side_enabled() and inputs[0].shape[0] <= SIDE_MAX_BATCH
@@ -149,9 +156,8 @@ class side_stream:
     def __enter__(self):
         if not self.on:
             return self
-        if _SIDE["stream"] is None:
-            _SIDE["stream"] = torch.cuda.Stream()
-        side = _SIDE["stream"]
+        e = _side_of_current()
+        side = e["stream"]
         self.main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(self.main)
@@ -160,7 +166,7 @@ class side_stream:
             if t is not None:
                 t.record_stream(side)
         torch.cuda.set_stream(side)
-        _SIDE["dirty"] = True
+        e["dirty"] = True
         return self
 
     def __exit__(self, *exc):
@@ -170,12 +176,63 @@ class side_stream:
 
 
 def side_join() -> None:
-    """The main stream waits for everything queued on the side stream (called before gradients are exchanged / applied)."""
-    if _SIDE["dirty"]:
+    """The current stream waits for everything queued on ITS side stream (called before gradients are exchanged / applied)."""
+    e = _SIDE.get(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    if e is not None and e["dirty"]:
         ev = torch.cuda.Event()
-        ev.record(_SIDE["stream"])
+        ev.record(e["stream"])
         torch.cuda.current_stream().wait_event(ev)
-        _SIDE["dirty"] = False
+        e["dirty"] = False
+
+
+# ---- a second stream for a whole network's passes ------------------------------------------------------------------------
+# At the data-parallel shard batch a conv launch fills the 256 CUs for 1-3 rounds of workgroups; the last, partly filled round
+# costs the fp32 kernels 11-17 % against the bs-128 step (111 vs 133 TF/s).  The discriminator and the style promoter are two
+# networks of the same size whose passes depend on each other nowhere between the generator's forward and the loss head, and
+# again between the loss head and the generator's backward: train_step queues S's fused forward (and later its backward sweep)
+# on this stream and D's / R's on the launch stream, so the tails of one network's launches are filled by the other's.
+# Same switch and conditions as the weight-grad side stream (fp32 mode, no kernel timing, not deterministic, small launches).
+NET_STREAM = _os.environ.get("SG_NET_STREAM", "1") == "1"
+_NET = {"stream": None}
+
+
+def net_stream_enabled(batch: int) -> bool:
+    return NET_STREAM and side_enabled() and batch <= SIDE_MAX_BATCH
+
+
+class net_stream:
+    """with ops.net_stream(inputs...) as ns: launches run on the network stream after everything queued so far on the launch
+    stream; ns.join(outputs...) afterwards makes the launch stream wait for them (and tells the allocator that the outputs,
+    allocated on the network stream, are read on the launch stream)."""
+
+    def __init__(self, *inputs):
+        self.inputs = inputs
+
+    def __enter__(self):
+        if _NET["stream"] is None:
+            _NET["stream"] = torch.cuda.Stream()
+        ns = _NET["stream"]
+        self.main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        ns.wait_event(ev)
+        for t in self.inputs:
+            if t is not None:
+                t.record_stream(ns)
+        torch.cuda.set_stream(ns)
+        return self
+
+    def __exit__(self, *exc):
+        self.done = torch.cuda.Event()
+        self.done.record(_NET["stream"])
+        torch.cuda.set_stream(self.main)
+        return False
+
+    def join(self, *outputs):
+        self.main.wait_event(self.done)
+        for t in outputs:
+            if t is not None:
+                t.record_stream(self.main)
 
 
 def _p(t: Optional[torch.Tensor]):

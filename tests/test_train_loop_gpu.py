@@ -354,3 +354,42 @@ def test_graph_captured_step_equals_eager_steps(dev, mode):
         # (third Adam step, beta_1 = 0: |update| <= lr sqrt(1 - 0.999^3) / sqrt(0.001) = 1.73 lr for a component whose history is ~0;
         #  stepping the other way in the two runs = 3.5 lr = 6.9e-4, measured exactly that on one component in bf16 mode)
         assert diff.max().item() <= 4 * 2e-4 and diff.mean().item() <= 5e-6, (m.name, diff.max().item(), diff.mean().item())
+
+
+def test_network_and_side_streams_do_not_change_the_step(dev):
+    """Small per-GPU batches queue S's passes on a second stream beside D's / R's (ops.net_stream) and every weight-grad launch on
+    a side stream of its sweep (ops.side_stream).  The same step (the B = 8 fixture, balancing on, all passes fused) with both
+    switched off must give the same 16 scalars (1e-5) and the same gradients of all four networks (3e-4 of the network's
+    largest gradient: float-atomic summation order) -- a missing event / join would show as stale or partial gradients."""
+    from tests import step_fixture as F
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
+    pb = F.make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=70.0)
+    B = pb["B"]
+    res = {}
+    old = (ops.NET_STREAM, ops.SIDE_WGRAD)
+    try:
+        for mode, on in (("streams", True), ("single", False)):
+            ops.NET_STREAM = ops.SIDE_WGRAD = on
+            assert ops.net_stream_enabled(3 * B) == on
+            NA._model_counter[0] = 0
+            NA.configure(device=dev, seed=9)
+            models, gan, nlg = F.load_models(NA, pb, dev)
+            G, D, R, S = (models[n] for n in ("G", "D", "R", "S"))
+            opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+            for rep in range(2):          # twice: the second step re-uses memory the first one freed on either stream
+                if rep:                   # same weights again (the first step's Adam update is undone)
+                    for n, m in models.items():
+                        m.store.load({k: v.float() for k, v in pb["P"][n].items()})
+                    ops.weights_changed()
+                out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0],
+                                    opts[1], opts[2], opts[3], pb["style"].float().numpy(), B, 128, net_loss.hinge, 1, 1, None, 10, "",
+                                    fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
+            res[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in models.items()})
+    finally:
+        ops.NET_STREAM, ops.SIDE_WGRAD = old
+    sa, ga = res["streams"]
+    sb, gb = res["single"]
+    assert np.all(np.abs(sa - sb) <= 1e-5 * np.maximum(1.0, np.abs(sb))), (sa, sb)
+    for n in ("D", "R", "S", "G"):
+        scale = gb[n].abs().max().item()
+        assert (ga[n] - gb[n]).abs().max().item() <= 3e-4 * scale, "%s gradients: %.3e vs scale %.3e" % (n, (ga[n] - gb[n]).abs().max().item(), scale)

@@ -358,10 +358,11 @@ def test_graph_captured_step_equals_eager_steps(dev, mode):
 
 def test_network_and_side_streams_do_not_change_the_step(dev):
     """Small per-GPU batches queue S's passes on a second stream beside D's / R's (ops.net_stream) and every weight-grad launch on
-    a side stream of its sweep (ops.side_stream).  The same step (the B = 8 fixture, all passes fused; no gradient balancing, whose
-    division by std(g_loss) amplifies float-atomic noise in G's gradient to 2e-3) with both switched off must give the same 16
-    scalars (1e-5) and the same gradients of all four networks (3e-4 of the network's largest gradient: float-atomic summation
-    order) -- a missing event / join would show as stale or partial gradients."""
+    a side stream of its sweep (ops.side_stream).  The same step (the B = 8 fixture, all passes fused, no gradient balancing) with
+    both switched off must give the same 16 scalars (1e-5) and the same gradients of all four networks -- a missing event / join
+    would show as stale or partial gradients.  Yardstick = the run-to-run noise of the SINGLE-stream step itself (two runs: float
+    atomics, amplified where a ReLU decision of the generator sits on the edge): |streams - single| <= max(3e-4 of the network's
+    largest gradient, 4 x |single - single'|); per-tensor report in gpurun_out/streams_vs_single.txt."""
     from tests import step_fixture as F
     from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
     pb = F.make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=70.0)
@@ -369,7 +370,7 @@ def test_network_and_side_streams_do_not_change_the_step(dev):
     res = {}
     old = (ops.NET_STREAM, ops.SIDE_WGRAD)
     try:
-        for mode, on in (("streams", True), ("single", False)):
+        for mode, on in (("streams", True), ("single", False), ("single2", False)):
             ops.NET_STREAM = ops.SIDE_WGRAD = on
             assert ops.net_stream_enabled(3 * B) == on
             NA._model_counter[0] = 0
@@ -385,12 +386,25 @@ def test_network_and_side_streams_do_not_change_the_step(dev):
                 out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0],
                                     opts[1], opts[2], opts[3], pb["style"].float().numpy(), B, 128, net_loss.hinge, 1, 0, None, 10, "",
                                     fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
-            res[mode] = (np.array(out, np.float64), {n: m.store.grad.clone() for n, m in models.items()})
+            res[mode] = (np.array(out, np.float64), {n: {k: m.store.g[k].clone() for k in m.store.trainable_names()} for n, m in models.items()})
     finally:
         ops.NET_STREAM, ops.SIDE_WGRAD = old
     sa, ga = res["streams"]
     sb, gb = res["single"]
+    _, gc = res["single2"]
     assert np.all(np.abs(sa - sb) <= 1e-5 * np.maximum(1.0, np.abs(sb))), (sa, sb)
+    lines, bad = [], []
     for n in ("D", "R", "S", "G"):
-        scale = gb[n].abs().max().item()
-        assert (ga[n] - gb[n]).abs().max().item() <= 3e-4 * scale, "%s gradients: %.3e vs scale %.3e" % (n, (ga[n] - gb[n]).abs().max().item(), scale)
+        scale = max(t.abs().max().item() for t in gb[n].values())
+        for k in gb[n]:
+            err = (ga[n][k] - gb[n][k]).abs().max().item()
+            noise = (gb[n][k] - gc[n][k]).abs().max().item()
+            lines.append("%s.%s: |streams - single| %.3e  |single - single'| %.3e  (largest gradient of the network %.3e)" % (n, k, err, noise, scale))
+            if err > max(3e-4 * scale, 4.0 * noise):
+                bad.append(lines[-1])
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        open("gpurun_out/streams_vs_single.txt", "w").write("\n".join(sorted(lines, key=lambda l: -float(l.split("|streams - single| ")[1].split()[0]))[:40]) + "\n")
+    except OSError:
+        pass
+    assert not bad, "\n".join(bad[:10])

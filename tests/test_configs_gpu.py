@@ -55,12 +55,13 @@ def test_generator_inference_matches_oracle(NA, dev, L, style_w):
 
 
 def test_c4_bucketed_step_against_oracle(NA, dev):
-    """Config c4 (variable width): one train_step with real words of L_r = 5, fakes of L_f = 4 (bucket_size 23) and
-    full-width 32x160 style images at B = 8 -- three different widths, so every reference call is its own pass -- against
-    the fp64 oracle with the calibrated bound (hinge, no balancing: the c4 setting)."""
+    """Config c4 (variable width): one train_step with real words of L_r = 3, fakes of L_f = 2 (bucket_size 23) and
+    full-width 32x160 style images at B = 4 -- three different widths, so every reference call is its own pass -- against
+    the fp64 oracle with the calibrated bound (hinge, no balancing: the c4 setting).  (Round 3: B 8 -> 4 and shorter words: the two
+    CPU evaluations of the oracle on 160-wide style images took 60-250 s of the GPU suite depending on the box's host.)"""
     from tests import step_fixture as F
-    pb = F.make_problem(B=8, L_r=5, L_f=4, style_w=160, seed=23, logit_scale=70.0)
-    check_step_against_calibrated_oracle(NA, dev, pb, "hinge", False, "c4_Lr5_Lf4", bucket_size=23)
+    pb = F.make_problem(B=4, L_r=3, L_f=2, style_w=160, seed=23, logit_scale=70.0)
+    check_step_against_calibrated_oracle(NA, dev, pb, "hinge", False, "c4_Lr3_Lf2", bucket_size=23)
 
 
 def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None):

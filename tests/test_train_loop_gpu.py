@@ -378,7 +378,7 @@ def test_network_and_side_streams_do_not_change_the_step(dev):
             models, gan, nlg = F.load_models(NA, pb, dev)
             G, D, R, S = (models[n] for n in ("G", "D", "R", "S"))
             opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
-            for rep in range(2):          # twice: the second step re-uses memory the first one freed on either stream
+            for rep in range(2 if on else 1):     # streams: twice -- the second step re-uses memory the first one freed on either stream
                 if rep:                   # same weights again (the first step's Adam update is undone)
                     for n, m in models.items():
                         m.store.load({k: v.float() for k, v in pb["P"][n].items()})

@@ -43,7 +43,12 @@ def _run_step(reducer, dev, balance):
     ops_det(True)
     NA._model_counter[0] = 0
     NA.configure(device=dev, seed=5, reducer=reducer)
-    G, D, R, S, gan = build_models((32, 160, 1), 128, (32, 8192), None, "B3", "B1", 52, None)
+    from scrabble_gan_amd import nn as _nn
+    _nn.FAST_INIT = True             # (scaled Gaussian instead of QR-orthogonal kernels: same seeds -> same weights in all three processes)
+    try:
+        G, D, R, S, gan = build_models((32, 160, 1), 128, (32, 8192), None, "B3", "B1", 52, None)
+    finally:
+        _nn.FAST_INIT = False
     for m in (G, D, S):                       # non-zero sigma so the attention path matters
         for k in m.store.names:
             if k.endswith(".sigma"):

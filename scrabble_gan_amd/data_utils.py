@@ -202,7 +202,7 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
         r_f, ctx_rf = R.forward(x_f, fake_t, il_f, L_f, training=True)
         d_r, ctx_dr = D.forward(images, nl.get("D.real"))
         s_my, ctx_smy = S.forward(style, nl.get("S.style"))
-        s_r, _ = S.forward(images, nl.get("S.real"))
+        s_r, ctx_sr = S.forward(images, nl.get("S.real"))
         r_r, ctx_rr = R.forward(images, labels_t, il_r, L_r, training=True)
 
     if use_ns:
@@ -210,6 +210,14 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
     if DEBUG_KEEP is not None:                                      # (tests: the recognizer's ReLU / max-pool decisions)
         DEBUG_KEEP["R_f"] = R.slice_ctx(ctx_R, 0, B) if (fuse and fuse_r) else ctx_rf
         DEBUG_KEEP["R_r"] = R.slice_ctx(ctx_R, B, 2 * B) if (fuse and fuse_r) else ctx_rr
+        if plain:                                                   # D / S contexts per reference call (fake, real / fake, style, real)
+            DEBUG_KEEP["D_f"], DEBUG_KEEP["D_r"] = (D.slice_ctx(ctx_D, 0, B), D.slice_ctx(ctx_D, B, 2 * B)) if fuse else (ctx_df, ctx_dr)
+            if fuse and fuse_style:
+                DEBUG_KEEP["S_f"], DEBUG_KEEP["S_my"], DEBUG_KEEP["S_r"] = (S.slice_ctx(ctx_S, i * B, (i + 1) * B) for i in range(3))
+            elif fuse:
+                DEBUG_KEEP["S_f"], DEBUG_KEEP["S_my"], DEBUG_KEEP["S_r"] = S.slice_ctx(ctx_S, 0, B), ctx_smy, S.slice_ctx(ctx_S, B, 2 * B)
+            else:
+                DEBUG_KEEP["S_f"], DEBUG_KEEP["S_my"], DEBUG_KEEP["S_r"] = ctx_sf, ctx_smy, ctx_sr
 
     # ---- losses, gradient balancing, statistics and the upstream gradients of all four targets (:418-442) ----
     mode = getattr(loss_fn, "mode", None)

@@ -139,25 +139,52 @@ def load_models(NA, pb, dev):
     return models, gan, nlg
 
 
+def _nl_pool_indices(nlc):
+    """The two max-pool selections (phi, g) of one NonLocalBlock call from its saved context (plain or one-segment form)."""
+    if isinstance(nlc, tuple) and len(nlc) == 2 and nlc[0] == "seg":
+        assert len(nlc[1]) == 1, "one NonLocalBlock call per sliced context"
+        nlc = nlc[1][0][2]
+    return [nlc[3].cpu(), nlc[5].cpu()]
+
+
+def _trunk_decisions(tctx):
+    """ReLU decisions (9) and NonLocalBlock max-pool selections (2) of one pass through a D-shaped trunk."""
+    ctxs, net = tctx
+    relu, pool = [], []
+    for (x, c1, _xp), nlc in ctxs:
+        relu += [(x > 0).cpu(), (c1 > 0).cpu()]
+        if nlc is not None:
+            pool += _nl_pool_indices(nlc)
+    relu.append((net > 0).cpu())
+    return relu, pool
+
+
 def hip_decisions(keep):
     """The ReLU / max-pool decisions the HIP forward passes took, from the contexts train_step saved (DEBUG_KEEP):
-    -> ({relu site: bool tensor}, {pool site: uint8 window positions}) for the generator (its 16 ReLU sites) and the two
-    recognizer calls (7 ReLU + 4 MaxPool2D sites each), indexed as RELU_RANGE / POOL_RANGE.
-    The style encoder applies its ReLUs in the consumers' operand loaders (decision = sign of the saved fp32 pre-activation);
-    the up blocks, the final BatchNorm and the recognizer's convolutions materialise relu(.) (decision = output > 0)."""
+    -> ({relu site: bool tensor}, {pool site: uint8 window positions}) for ALL sites of the step: the generator (16 ReLU, 4 pools),
+    every discriminator / style-promoter call (9 + 2 each) and both recognizer calls (7 + 4 each), indexed as RELU_RANGE /
+    POOL_RANGE.  The D-shaped trunks apply their ReLUs in the consumers' operand loaders (decision = sign of the saved fp32
+    pre-activation); the up blocks, the final BatchNorm and the recognizer's convolutions materialise relu(.) (decision =
+    output > 0)."""
     tctx, h, z, y, up_ctx, bctx, yb, img, S = keep["ctx_g"]
-    ctxs, net = tctx
-    dec = []
-    for (x, c1, _xp), _nl in ctxs:
-        dec += [x > 0, c1 > 0]
-    dec.append(net > 0)
-    for (c, _nl) in up_ctx:
+    relu, pool = {}, {}
+    dec, pl = _trunk_decisions(tctx)
+    for (c, nlc) in up_ctx:
         x_in, c1, c2, stride = c
-        dec += [c1[1] > 0, c2[1] > 0]
-    dec.append(yb > 0)
-    assert len(dec) == G_RELU_SITES
-    relu = {i: d.cpu() for i, d in enumerate(dec)}
-    pool = {}
+        dec += [(c1[1] > 0).cpu(), (c2[1] > 0).cpu()]
+        if nlc is not None:
+            pl += _nl_pool_indices(nlc)
+    dec.append((yb > 0).cpu())
+    assert len(dec) == G_RELU_SITES and len(pl) == 4
+    relu.update(enumerate(dec))
+    pool.update(enumerate(pl))
+    for tag in ("D_f", "S_f", "D_r", "S_my", "S_r"):
+        if tag not in keep:
+            continue
+        dec, pl = _trunk_decisions(keep[tag][0])
+        assert len(dec) == 9 and len(pl) == 2
+        relu.update((RELU_RANGE[tag][0] + i, d) for i, d in enumerate(dec))
+        pool.update((POOL_RANGE[tag][0] + i, d) for i, d in enumerate(pl))
     for tag in ("R_f", "R_r"):
         acts = keep[tag][0]
         r0, p0 = RELU_RANGE[tag][0], POOL_RANGE[tag][0]

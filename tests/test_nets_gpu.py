@@ -370,7 +370,7 @@ def test_kernel_reg_applied(dev, which):
             M.backward(ctx, dimg.float().to(dev))
             at = net_atol([v.grad for v in lv.values()])
             for k, v in lv.items():
-                close(M.store.g[k], v.grad, 1e-2, "grad " + k, at)
+                close_grad(M.store.g[k], v.grad, 1e-2, "grad " + k, at)        # (test_generator's criterion: batch-of-2 BN, ReLU flips)
     finally:
         NA.configure(kernel_reg_mode="reference")
 
@@ -459,23 +459,21 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
                 # ReLU / max-pool DECISIONS: a pre-activation within fp32 rounding of zero may fall on the other side than in
                 # fp64 (for the oracle's fp32 evaluation as well, at other elements).  One flipped element of a
                 # ConditionalBatchNorm over 32 pixels per sample moves one column of dgamma / dbeta and one 32-entry row of
-                # the filter-bank gradient by a few percent and nothing else.  Such isolated outliers (at most 64 elements
-                # of a tensor, the whole-tensor L2 criterion above still holding) are tolerated; anything wider is not.
-                # The exemption has to PROVE that claim: see the counterfactual oracle below.
+                # the filter-bank gradient by a few percent and nothing else; one flipped activation in front of a 3x3 conv of
+                # D / S / R moves up to 9 x Cout entries of that conv's weight gradient.  Such outliers are admitted ONLY through
+                # the counterfactual oracle below, which has to reproduce them.
                 n_out = int((diff > bound).sum().item())
                 flips.append("%s.%s: %d element(s) above the bound, max %.3e (bound %.3e)" % (net, k, n_out, err, bound))
-                if n_out > 64 or net not in ("G", "R"):
-                    bad.append("%s grad %s: |HIP-fp64| %.3e > bound %.3e at %d elements (oracle fp32 err %.3e, scale %.3e)" % (net, k, err, bound, n_out, e32, scale))
-                else:
-                    exempted.append((net, k, bound, at))
-    # ---- proof of the outlier exemption.  (1) Every ReLU / max-pool decision of the HIP generator and recognizer passes that
+                exempted.append((net, k, bound, at))        # (any network, any count: the counterfactual below decides)
+    # ---- proof of the outlier exemption.  (1) Every ReLU / max-pool decision of the HIP passes -- all 75 ReLU and 22 MaxPool2D
+    # sites of the step: G, both D calls, the three S calls, both R calls -- that
     # differs from the fp64 oracle's must sit within fp32 rounding of the boundary: |fp64 pre-activation| (resp. the gap between
     # the chosen window element and the window maximum) <= 2e-5 x the site's largest value (checked whether or not a tensor
     # needed the exemption -- a decision that differs AWAY from the boundary is a wrong activation, not rounding).  (2) The fp64
-    # oracle is re-evaluated with exactly those decisions imposed (the counterfactual: y = x * HIP's mask at the 30 ReLU
-    # sites, y = HIP's window element at the 8 MaxPool2D sites, backward routing included); against IT every exempted tensor
-    # must meet its calibrated bound at ALL elements.  An indexing error that touches <= 64 elements survives neither.
-    # (Decisions inside D / S are not imposed: an outlier in their gradients is not exempted at all.)
+    # oracle is re-evaluated with exactly those decisions imposed (the counterfactual: y = x * HIP's mask at the flipped ReLU
+    # sites, y = HIP's window element at the flipped MaxPool2D sites, backward routing included); against IT every tensor that
+    # had outliers -- of any network, however many elements -- must meet its calibrated bound at ALL elements.  An indexing
+    # error survives neither, whatever the number of elements it touches.
     sites64, pools64 = cal["relu_sites64"], cal["pool_sites64"]
     forced, forced_pool, n_flip = {}, {}, 0
     for i, dec in sorted(hip_relu.items()):
@@ -507,7 +505,7 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
         n_flip += nf
     if exempted:
         if n_flip == 0:
-            bad.append("outliers in %s but NO ReLU / max-pool decision of G or R differs from fp64: not a decision flip" % [k for _, k, _, _ in exempted])
+            bad.append("outliers in %s but NO ReLU / max-pool decision of the step differs from fp64: not a decision flip" % [k for _, k, _, _ in exempted])
         else:
             _, g_cf, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced, forced_pool=forced_pool)
             for net, k, bound, at in exempted:

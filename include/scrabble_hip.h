@@ -73,6 +73,31 @@ int sg_conv2d_fwd_v2(const float* x, const float* wt_fwd, const float* bias, con
 int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, float* dx,
                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
+/* ---- Winograd-domain fp32 3x3 convolutions, F(2x2, 3x3) (round 3; conv_winograd.hip): stride-1 SAME 3x3 convolutions with
+ *      H, W even, reduction channels % 32 == 0 and output channels % 64 == 0 as sixteen [tiles x K] x [K x N] products
+ *      (16 / 36 of the direct multiplies) between an input and an output transform.  Same contracts, flags and results as
+ *      sg_conv2d_fwd / sg_conv2d_bwd_data (resnet_ops.py:65,98,103) up to fp32 rounding (the transforms add <= 4 terms per
+ *      dimension); SG_ERR_UNSUPPORTED for other shapes (caller: the direct entry points).
+ *        sg_wino_filter(w_nk [3][3][N][K], u [16][N][K], N, K, flip): transformed filter, once per optimizer step --
+ *            forward : w_nk = sg_transpose_filter(w, 9, K = Cin, N = Cout) ([tap][Cout][Cin]), flip = 0;
+ *            data-grad: w_nk = w [3,3,Cin,Cout] itself (N = Cin, K = Cout),              flip = 1 (taps mirrored);
+ *        workspace: sg_wino_workspace_bytes(B, H, W, Cin, Cout) bytes of device memory, caller-provided, contents scratch:
+ *            V [16][Tp][K] followed by Mt [16][Tp][N], Tp = B H/2 W/2 rounded up to 256.
+ *      The three steps are also exported one by one (the host side times the HBM-bound transforms apart from the
+ *      matrix-bound product): sg_wino_input (x [B,H,W,C] -> V, relu != 0 applies max(.,0) to x), sg_wino_gemm
+ *      (Mt[f] = V[f] U[f]^T for the 16 frequencies in one grouped launch), sg_wino_output (Mt -> y with bias + bias2, ReLU
+ *      mask, SG_ACCUM, SG_RELU_OUT). */
+long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, void* stream);
+int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream);
+int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask,
+                   int B, int H, int W, int N, int flags, void* stream);
+int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, void* stream);
+int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, const float* bias2, float* y,
+                       int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx,
+                            int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+
 /* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
  *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale
  *      (nullable, [n / rowlen], rowlen % 8 == 0) multiplies row r by rowscale[r] first (the per-sample factors of the shared

@@ -20,38 +20,13 @@
 //     and this stage is free, so the DMAs of tile t+2 are issued there and spread over the following k-steps, while the
 //     last k-step's MFMAs already run on prefetched fragments of tile t+1's first step.
 // Reduction order: channel-chunk-major, taps innermost (the 3x3 neighbourhood of a pixel row stays in L2).
-#include "sg_conv.h"
+#include "sg_conv2.h"
 #include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
-
-#define SG2_IDENT_OUT 32
-
-struct SgIgemm2Args {
-  const u16* a;        // bf16 activation operand, NHWC [Bn, Ha, Wa, Ca], Ca % 64 == 0
-  const u16* w;        // packed bf16 filter [tap][N][Ca] (sg_pack_filter_bf16), N % 64 == 0
-  float* out;          // fp32 NHWC [Bn, Ho, Wo, N]
-  u16* out16;          // nullable: bf16 copy of the result (after bias / mask / ReLU), same layout
-  const float* bias;
-  const float* bias2;
-  const float* mask;   // nullable, fp32, same shape as out: result := 0 where mask <= 0
-  const u16* mask16;   // nullable alternative to `mask`: the same tensor as bf16 (sign and zero are what matter)
-  const float* amax_a; // fp8 operands only: device scalars max|activation| and max|filter| behind the per-tensor scales
-  const float* amax_w; //   (operand = fp8(value * 448 / amax)); the epilogue multiplies the sums by amax_a * amax_w / 448^2
-  float* amax_out;     // nullable (config c5): amax_out[0] = max(., max |result|), amax_out[1] = max(., max |amax_rowscale[b] * result|)
-  const float* amax_rowscale;   //   -- the per-tensor scales of the NEXT fp8 launch that reads the result, taken while it is written
-  int Bn, Ha, Wa, Ca;
-  int Hg, Wg, a_sy, a_sx;
-  int Ho, Wo, N, o_sy, o_sx, o_oy, o_ox;
-  int ntaps, flags;
-  int full_tiles, tail_split, n_tiles_total;
-  SgTap taps[SG_MAX_TAPS];   // w_off in elements of the packed filter
-};
-
 __device__ __attribute__((aligned(256))) unsigned int sg2_zero_page[64];      // 256 bytes of zeros (never written)
 
 __device__ __forceinline__ int sg2_xcd_remap(int orig, int nwg) {
@@ -214,6 +189,8 @@ __global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_ker
   }
   const int m0 = (wg / n_tiles) * BM;
   const int n0 = (wg % n_tiles) * BN;
+  const int grp = p.group_rows ? m0 / p.group_rows : 0;      // (uniform: a tile lies inside one group)
+  const int grp_row0 = grp * p.group_rows;
   const int kchunks = p.Ca / BK;
   const int KT_all = p.ntaps * kchunks;
   const int kt_begin = (int)(((long)KT_all * split) / nsplit);
@@ -229,7 +206,7 @@ __global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_ker
     const int chunk = lslot ^ ((r >> 1) & 7);
     const int m = m0 + r;
     const bool ok = m < M;
-    const int mm = ok ? m : 0;
+    const int mm = ok ? m - grp_row0 : 0;
     const int b = mm / HW;
     const int rem = mm - b * HW;
     const int yg = rem / p.Wg;
@@ -274,9 +251,9 @@ __global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_ker
     lc0 += wrap ? BK : 0;
     set_cursor();
   };
-  const unsigned long long a_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.a);
+  const unsigned long long a_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.a) + (unsigned long long)grp * (unsigned long long)p.a_group_bytes;
   const unsigned long long z_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(zero);
-  const unsigned long long w_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.w);
+  const unsigned long long w_base64 = (unsigned long long)reinterpret_cast<uintptr_t>(p.w) + (unsigned long long)grp * (unsigned long long)p.w_group_bytes;
   // part q (0..3) of the tile at the cursor into stage `st`: A rows of instruction q and B rows of instruction q
   auto issue_part = [&](int st, int q) {
     const bool ok = (a_msk[q] & cur_bit) != 0;
@@ -810,15 +787,20 @@ static bool sg2_prefer_128(const SgIgemm2Args& a, long m_tiles) {
 
 // -> SG_OK, and *twin_rows_done = number of leading output rows (pixels) whose bf16 copy the kernel wrote itself (the
 // rows of reduction-split tiles are summed by atomics: their bf16 copy needs a convert pass afterwards)
-static int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done, int es = 2) {
+int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_rows_done, int es) {
   SgIgemm2Args a = a_in;
   if ((a.Ca % (128 / es)) || (a.N % 64) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
   if (es == 1 && ((a.N % 256) || !a.amax_a || !a.amax_w)) return SG_ERR_UNSUPPORTED;
-  const long a_bytes = (long)es * a.Bn * a.Ha * a.Wa * a.Ca;
+  if (a.group_rows && ((a.group_rows % SG2_BM) || a.ntaps != 1 || a.Ha != 1 || a.Wa != 1 || a.Hg != 1 || a.Wg != 1 || a.Ho != 1 || a.Wo != 1 || a.out16 ||
+                       a.mask || a.mask16 || a.amax_out || (long)a.Bn % a.group_rows))
+    return SG_ERR_ARG;      // (grouped launches: plain [rows, Ca] x [N, Ca]^T products per group)
+  const long a_bytes = (long)es * (a.group_rows ? a.group_rows : a.Bn) * a.Ha * a.Wa * a.Ca;
   long w_elems = 0;
   for (int t = 0; t < a.ntaps; ++t) w_elems = a.taps[t].w_off > w_elems ? a.taps[t].w_off : w_elems;
   w_elems += (long)a.N * a.Ca;
-  if (a_bytes >= (1L << 32) - 64 || es * w_elems >= (1L << 32) - 64 || (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) return SG_ERR_UNSUPPORTED;
+  if (a_bytes >= (1L << 32) - 64 || es * w_elems >= (1L << 32) - 64 || (!a.group_rows && (long)a.Bn * a.Ho * a.Wo * a.N >= (1L << 31)) ||
+      (long)a.Bn * a.Hg * a.Wg >= (1L << 31) - 256)
+    return SG_ERR_UNSUPPORTED;      // (grouped launches index the result with 64-bit row offsets only: identity layout)
   if (a.o_sy == 1 && a.o_sx == 1 && a.o_oy == 0 && a.o_ox == 0 && a.Ho == a.Hg && a.Wo == a.Wg) a.flags |= SG2_IDENT_OUT;
   // Tile width: the widest one that divides N, unless the launch cannot be cut along the reduction (a fused output ReLU
   // rules the float-atomic tail split out) and a narrower tile fills the 256 CUs' rounds better.  Relative tile times:
@@ -891,7 +873,7 @@ extern "C" int sg_conv2d_fwd_bf16v2(const void* x16, const void* wp_fwd, const f
   for (int ky = 0; ky < kh; ++ky)
     for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ky - ph, kx - pw, (ky * kw + kx) * Cin * Cout};
   long done = 0;
-  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done);
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 2);
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
 }
 
@@ -910,7 +892,7 @@ extern "C" int sg_conv2d_bwd_data_bf16v2(const void* dy16, const void* wp_bwd, c
   for (int ky = 0; ky < kh; ++ky)
     for (int kx = 0; kx < kw; ++kx) a.taps[ky * kw + kx] = SgTap{ph - ky, pw - kx, (ky * kw + kx) * Cin * Cout};
   long done = 0;
-  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done);
+  const int rc = sg_launch_igemm_bf16v2(a, (hipStream_t)stream, &done, 2);
   return rc != SG_OK ? rc : finish_twin(a, done, (hipStream_t)stream);
 }
 

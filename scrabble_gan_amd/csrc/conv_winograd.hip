@@ -1,0 +1,238 @@
+// Winograd-domain 3x3 convolutions, F(2x2, 3x3), fp32 (config c2 of BASELINE.json: the fp32 matrix rate bounds the step, so
+// the lever left is the NUMBER of products).  A stride-1 SAME 3x3 convolution over 2x2 output tiles
+//     Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2015; d = the 4x4 input patch of the tile, g = the 3x3 filter)
+// needs 16 products per tile, channel pair and output pair where the direct form needs 36: the sixteen "frequencies" are
+// sixteen independent [tiles x Cin] x [Cin x Cout] matrix products.  Three steps:
+//   1. input transform   x [B,H,W,C]           -> V [16][Tp][C]      (k_wino_in: adds only; the operand ReLU of the pre-activation
+//                                                                     blocks is applied to the loaded values)
+//   2. ONE grouped launch of the DMA-fed implicit-GEMM kernel (conv_bf16v2.hip, fp32 operands, v_mfma_f32_32x32x2_f32): group f
+//      multiplies V[f] with the transformed filter U[f] = [N][K] into Mt[f] -- the same loop, tiles and epilogue as the direct
+//      fp32 launch, as a 1x1 convolution over 16 Tp "pixels";
+//   3. output transform  Mt [16][Tp][N]        -> y [B,H,W,N]        (k_wino_out: adds, then the conv entry points' epilogue --
+//                                                                     bias, ReLU mask of the data-grad, accumulate, output ReLU).
+// The data-grad of such a convolution is the same convolution of dy with the spatially flipped filter and the channel roles
+// swapped, so it runs through the same three steps with U built from w [kh,kw,Cin,Cout] as it lies (flip = 1).
+// The transforms are HBM-bound sweeps (V and Mt are 4x the activation each); the products drop to 16 / 36 of the direct count.
+// Numerics: exact fp32 products and fp32 accumulation like the direct kernels; the transforms add at most four terms per
+// dimension and the filter transform scales by 1/2 and 1/4 (exact), so the error grows by a small constant factor over the
+// direct form (tests/test_winograd_gpu.py states the bound against the fp64 oracle).
+// Tiles: t = (b * H/2 + ty) * W/2 + tx, T = B H/2 W/2 of them, planes padded to Tp = T rounded up to 256 rows (the GEMM
+// kernel's tile height: a tile never straddles two frequencies); the pad rows are never written nor read back.
+#include "sg_conv2.h"
+
+#define WINO_F 16
+
+static inline long wino_tp(long T) { return (T + 255) / 256 * 256; }
+
+// ---- filter transform: in [3][3][N][K] (fp32) -> U [16][N][K];  flip != 0 reads tap (2 - a, 2 - b) for (a, b)
+__global__ __launch_bounds__(256) void k_wino_filter(const float* __restrict__ in, float* __restrict__ U, long NK, int flip) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < NK; e += (long)gridDim.x * 256) {
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = in[(size_t)((flip ? 2 - a : a) * 3 + (flip ? 2 - b : b)) * NK + e];
+    float h[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      h[0][b] = g[0][b];
+      h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      h[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      U[(size_t)(i * 4 + 0) * NK + e] = h[i][0];
+      U[(size_t)(i * 4 + 1) * NK + e] = 0.5f * (h[i][0] + h[i][1] + h[i][2]);
+      U[(size_t)(i * 4 + 2) * NK + e] = 0.5f * (h[i][0] - h[i][1] + h[i][2]);
+      U[(size_t)(i * 4 + 3) * NK + e] = h[i][2];
+    }
+  }
+}
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// ---- input transform: one thread = one tile x four channels (a wave = 256 consecutive channels of a tile: 1 KB per access)
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, long T, long Tp) {
+  const int C4 = C >> 2, H2 = H >> 1, W2 = W >> 1;
+  const long items = T * C4;
+  const size_t plane = (size_t)Tp * C;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / C4;
+    const int c = (int)(it - t * C4) * 4;
+    const int tx = (int)(t % W2);
+    const long r = t / W2;
+    const int ty = (int)(r % H2);
+    const long b = r / H2;
+    float4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int iy = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ix = 2 * tx - 1 + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        d[i][j] = v;
+      }
+    }
+    // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+    float4 u[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u[0][j] = f4_sub(d[0][j], d[2][j]);
+      u[1][j] = f4_add(d[1][j], d[2][j]);
+      u[2][j] = f4_sub(d[2][j], d[1][j]);
+      u[3][j] = f4_sub(d[1][j], d[3][j]);
+    }
+    float* out = V + (size_t)t * C + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 0) * plane) = f4_sub(u[i][0], u[i][2]);
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 1) * plane) = f4_add(u[i][1], u[i][2]);
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 2) * plane) = f4_sub(u[i][2], u[i][1]);
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 3) * plane) = f4_sub(u[i][1], u[i][3]);
+    }
+  }
+}
+
+// ---- output transform + the conv entry points' epilogue: one thread = one tile x four output channels
+__global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mt, float* __restrict__ y, const float* __restrict__ bias,
+                                                  const float* __restrict__ bias2, const float* __restrict__ mask, int H, int W, int N, long T,
+                                                  long Tp, int flags) {
+  const int N4 = N >> 2, H2 = H >> 1, W2 = W >> 1;
+  const long items = T * N4;
+  const size_t plane = (size_t)Tp * N;
+  const bool accum = (flags & SG_ACCUM) != 0, relu_out = (flags & SG_RELU_OUT) != 0;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / N4;
+    const int n = (int)(it - t * N4) * 4;
+    const int tx = (int)(t % W2);
+    const long r = t / W2;
+    const int ty = (int)(r % H2);
+    const long b = r / H2;
+    const float* src = Mt + (size_t)t * N + n;
+    float4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(src + (size_t)(i * 4 + j) * plane);
+    // A^T m A with A^T = [1 1 1 0; 0 1 -1 -1]
+    float4 q[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[0][j] = f4_add(f4_add(m[0][j], m[1][j]), m[2][j]);
+      q[1][j] = f4_sub(f4_sub(m[1][j], m[2][j]), m[3][j]);
+    }
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bs = f4_add(bs, *reinterpret_cast<const float4*>(bias + n));
+    if (bias2) bs = f4_add(bs, *reinterpret_cast<const float4*>(bias2 + n));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 v = j == 0 ? f4_add(f4_add(q[i][0], q[i][1]), q[i][2]) : f4_sub(f4_sub(q[i][1], q[i][2]), q[i][3]);
+        v = f4_add(v, bs);
+        const size_t idx = ((size_t)(b * H + 2 * ty + i) * W + 2 * tx + j) * N + n;
+        if (mask) {
+          const float4 k = *reinterpret_cast<const float4*>(mask + idx);
+          if (k.x <= 0.f) v.x = 0.f;
+          if (k.y <= 0.f) v.y = 0.f;
+          if (k.z <= 0.f) v.z = 0.f;
+          if (k.w <= 0.f) v.w = 0.f;
+        }
+        if (accum) v = f4_add(v, *reinterpret_cast<const float4*>(y + idx));
+        if (relu_out) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        *reinterpret_cast<float4*>(y + idx) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI (include/scrabble_hip.h)
+// ------------------------------------------------------------------------------------------
+static bool wino_shape_ok(int B, int H, int W, int K, int N) {
+  return B > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && K > 0 && N > 0 && !(K % 32) && !(N % 64);
+}
+
+extern "C" long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0) return 0;
+  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  return (long)sizeof(float) * WINO_F * Tp * ((long)Cin + Cout);
+}
+
+extern "C" int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, void* stream) {
+  if (!w_nk || !u || N <= 0 || K <= 0) return SG_ERR_ARG;
+  const long NK = (long)N * K;
+  SG_KERNEL(k_wino_filter, dim3(sg_grid_for(NK, 256)), dim3(256), 0, (hipStream_t)stream, w_nk, u, NK, flip);
+  return sg_launch_status();
+}
+
+// ---- the three steps as separate entry points (the host times them apart: two HBM-bound sweeps around one matrix-bound launch)
+extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, void* stream) {
+  if (!x || !V) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, C, 64)) return SG_ERR_UNSUPPORTED;
+  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  hipStream_t s = (hipStream_t)stream;
+  if (relu) SG_KERNEL(k_wino_in<true>, dim3(sg_grid_for(T * (C / 4), 256)), dim3(256), 0, s, x, V, H, W, C, T, Tp);
+  else SG_KERNEL(k_wino_in<false>, dim3(sg_grid_for(T * (C / 4), 256)), dim3(256), 0, s, x, V, H, W, C, T, Tp);
+  return sg_launch_status();
+}
+
+extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream) {
+  if (!V || !u || !Mt) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, K, N)) return SG_ERR_UNSUPPORTED;
+  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  if (WINO_F * Tp >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
+  SgIgemm2Args g{};
+  g.a = reinterpret_cast<const u16*>(V);
+  g.w = reinterpret_cast<const u16*>(u);
+  g.out = Mt;
+  g.Bn = (int)(WINO_F * Tp); g.Ha = 1; g.Wa = 1; g.Ca = K; g.Hg = 1; g.Wg = 1; g.a_sy = 1; g.a_sx = 1;
+  g.Ho = 1; g.Wo = 1; g.N = N; g.o_sy = 1; g.o_sx = 1; g.o_oy = 0; g.o_ox = 0;
+  g.ntaps = 1; g.flags = 0;
+  g.taps[0] = SgTap{0, 0, 0};
+  g.group_rows = (int)Tp;
+  g.a_group_bytes = (long)sizeof(float) * Tp * K;
+  g.w_group_bytes = (long)sizeof(float) * N * K;
+  return sg_launch_igemm_bf16v2(g, (hipStream_t)stream, nullptr, 4);
+}
+
+extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask, int B, int H, int W, int N,
+                              int flags, void* stream) {
+  if (!Mt || !y) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, 32, N) || (flags & (SG_TANH_OUT | SG_RELU_IN))) return SG_ERR_UNSUPPORTED;
+  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  SG_KERNEL(k_wino_out, dim3(sg_grid_for(T * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+  return sg_launch_status();
+}
+
+// a [B,H,W,K] -> out [B,H,W,N] through the three steps; u [16][N][K]
+static int wino_conv(const float* a, const float* u, const float* bias, const float* bias2, const float* mask, float* out, int B, int H, int W,
+                     int K, int N, int flags, void* workspace, long workspace_bytes, hipStream_t s) {
+  if (!a || !u || !out || !workspace) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, K, N) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
+  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  if (workspace_bytes < (long)sizeof(float) * WINO_F * Tp * ((long)K + N)) return SG_ERR_ARG;
+  float* V = reinterpret_cast<float*>(workspace);
+  float* Mt = V + (size_t)WINO_F * Tp * K;
+  int rc = sg_wino_input(a, V, B, H, W, K, (flags & SG_RELU_IN) != 0, s);
+  if (rc != SG_OK) return rc;
+  rc = sg_wino_gemm(V, u, Mt, B, H, W, K, N, s);
+  if (rc != SG_OK) return rc;
+  return sg_wino_output(Mt, out, bias, bias2, mask, B, H, W, N, flags & ~SG_RELU_IN, s);
+}
+
+extern "C" int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, const float* bias2, float* y, int B, int H, int W,
+                                  int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
+  return wino_conv(x, u_fwd, bias, bias2, nullptr, y, B, H, W, Cin, Cout, flags, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx, int B, int H, int W, int Cin,
+                                       int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
+  if (flags & (SG_RELU_IN | SG_RELU_OUT)) return SG_ERR_ARG;
+  return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, workspace, workspace_bytes, (hipStream_t)stream);
+}

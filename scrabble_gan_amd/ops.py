@@ -508,6 +508,14 @@ def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
     kh, kw, Cin, Cout = w.shape
+    if kind in ("wino_fwd", "wino_bwd"):   # Winograd-domain filters U [16][N][K] (conv_winograd.hip)
+        out = torch.empty(16, Cout * Cin, device=w.device, dtype=torch.float32)
+        if kind == "wino_fwd":
+            call("sg_wino_filter", _p(packed_filter(w, "fwd_f32t")), _p(out), Cout, Cin, 0, _stream())
+        else:
+            call("sg_wino_filter", _p(w), _p(out), Cin, Cout, 1, _stream())
+        _PACK_CACHE[key] = (w, out)
+        return out
     out = None if kind in ("bwd_f32", "fwd_f32t") else torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
     if kind in ("bwd_f32", "fwd_f32t"):   # fp32 [kh,kw,Cout,Cin]: per tap [N = Cout][K = Cin] for the second-generation forward
         out = torch.empty(kh, kw, Cout, Cin, device=w.device, dtype=torch.float32)   # launch (and the old transposed data-grad option)
@@ -687,6 +695,54 @@ def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool, pixels: int) -> bool
     return tiles >= F32_V2_MIN_TILES and (F32_V2_MIN_TILES == 0 or kh * kw * K >= 1024)
 
 
+# ---- Winograd-domain fp32 3x3 convolutions (conv_winograd.hip) --------------------------------------------------------
+USE_WINOGRAD = _os.environ.get("SG_WINOGRAD", "1") == "1"
+WINO_MIN_K = int(_os.environ.get("SG_WINO_MIN_K", "512"))     # reduction channels from which the 16 / 36 product count pays for the
+WINO_MIN_N = int(_os.environ.get("SG_WINO_MIN_N", "256"))     # two transform sweeps (tests set both to 32 / 64)
+_WINO_WS = {}              # raw stream handle -> scratch buffer (V and Mt of the launch in flight on that stream)
+
+
+def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
+    return (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
+            and K % 32 == 0 and N % 64 == 0 and K >= WINO_MIN_K and N >= WINO_MIN_N)
+
+
+def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    """Scratch for one Winograd-domain convolution, one buffer per stream (launches of one stream run in order, so the next
+    convolution may overwrite it), grown to the largest request."""
+    key = _stream()
+    buf = _WINO_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _WINO_WS.pop(key, None)
+        buf = None
+        buf = torch.empty(nbytes, device=like.device, dtype=torch.uint8)
+        _WINO_WS[key] = buf
+    return buf
+
+
+def _wino_conv(a, u, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flags: int, tag) -> None:
+    """out [B,H,W,N] = conv3x3_same(a [B,H,W,K]) through input transform -> 16 grouped products -> output transform."""
+    B, H, W, _ = a.shape
+    T = B * (H // 2) * (W // 2)
+    Tp = -(-T // 256) * 256
+    ws = _wino_workspace(lib().sg_wino_workspace_bytes(B, H, W, K, N), a)
+    V = ws.data_ptr()
+    Mt = V + 4 * 16 * Tp * K
+    s = _stream()
+    with _hbm("wino_transform", a, flops=0.0) as _:
+        if PROFILER is not None and PROFILER.wants("wino_transform"):
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * K
+        call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), s)
+    with _timed("igemm", 2.0 * 16 * Tp * K * N, False, tag):
+        if PROFILER is not None and PROFILER.wants("igemm"):
+            PROFILER.nbytes["igemm"] = PROFILER.nbytes.get("igemm", 0.0) + 4.0 * 16 * (Tp * K + N * K + Tp * N)
+        call("sg_wino_gemm", V, _p(u), Mt, B, H, W, K, N, s)
+    with _hbm("wino_transform", out, mask, flops=0.0):
+        if PROFILER is not None and PROFILER.wants("wino_transform"):
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * N
+        call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags, s)
+
+
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
     return USE_V2 and _low() and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
 
@@ -711,6 +767,10 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
         if GHOST_NAN:
             out.fill_(float("nan"))
         _TWINS[(out.untyped_storage().data_ptr(), "ghost")] = (out,)
+    if _wino_ok(Cin, Cout, kh, kw, same, H, W) and not tanh_out:
+        _wino_conv(x, packed_filter(w, "wino_fwd"), out, bias, bias2, None, Cin, Cout, relu_in, _flags(False, accum, relu_out),
+                   ("wino_fwd", B, Ho, Wo, Cin, Cout, kh))
+        return out
     with _timed("igemm_fp8" if use8 else "igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("fwd", B, Ho, Wo, Cin, Cout, kh), (x, w, out)):
         if use8:
@@ -757,6 +817,10 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
     use8 = _fp8_ok(Cout, Cin, kh, kw, same)
+    if _wino_ok(Cout, Cin, kh, kw, same, H, W) and tuple(dy.shape[1:3]) == (H, W):
+        _wino_conv(dy, packed_filter(w, "wino_bwd"), out, None, None, mask, Cout, Cin, False, _flags(accum=accum),
+                   ("wino_dgrad", B, H, W, Cin, Cout, kh))
+        return out
     with _timed("igemm_fp8" if use8 else "igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
                 ("dgrad", B, H, W, Cin, Cout, kh), (dy, w, out, mask)):
         if use8:

@@ -1,0 +1,160 @@
+"""Winograd-domain fp32 3x3 convolutions (scrabble_gan_amd/csrc/conv_winograd.hip; round 3) against the fp64 oracle.
+
+The path replaces the direct implicit-GEMM launch of the stride-1 SAME 3x3 convolutions over >= 512 reduction channels in fp32
+mode (resnet_ops.py:65,98,103 of the reference: the ResNet blocks' convolutions) -- same contract, 16 / 36 of the multiplies.
+Tolerances (max |got - ref| <= tol * max |ref|): 2e-5 against the fp64 oracle, the bound the direct fp32 kernels are held to
+(tests/test_fullsize_gpu.py); the measured error is printed -- the transforms add <= 4 terms per dimension, so the Winograd
+form's rounding error is a small multiple of the direct form's.  Launch-geometry rows of tests/test_fullsize_gpu.py (f32 mode) and
+the whole-network / train_step tests run through this path too (ops._wino_ok)."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from oracle import scrabble_oracle as O  # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def wino_everywhere():
+    """Every eligible shape (K % 32 == 0, N % 64 == 0, even H and W) through the Winograd path."""
+    from scrabble_gan_amd import ops
+    old = (ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD)
+    ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD = 32, 64, True
+    yield ops
+    ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD = old
+
+
+def _close(got, ref, tol, name):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item() + 1e-30
+    print("%s: rel err %.3e" % (name, err / scale))
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
+
+
+# B, H, W, Cin, Cout: one tile per sample; tile counts below / not a multiple of the 256-row plane padding; odd batches; the
+# recognizer-like wide rows; Cin != Cout both ways
+SMALL = [(1, 2, 2, 32, 64), (3, 2, 4, 64, 64), (5, 4, 10, 96, 128), (2, 8, 40, 128, 64), (7, 6, 6, 32, 192), (2, 16, 80, 64, 128),
+         (33, 4, 20, 256, 256)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SMALL)
+def test_forward_and_data_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cout):
+    ops = wino_everywhere
+    assert ops._wino_ok(Cin, Cout, 3, 3, True, H, W)
+    dgrad_too = ops._wino_ok(Cout, Cin, 3, 3, True, H, W)      # (the data-grad's output channels are Cin: % 64)
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + H * W + Cin)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b1 = torch.randn(Cout, device=dev, generator=g)
+    b2 = torch.randn(Cout, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    prev = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    xd, wd, dyd = x.double().cpu(), w.double().cpu(), dy.double().cpu()
+    # forward: plain; operand ReLU + two biases; accumulate; output ReLU
+    _close(ops.conv2d_fwd(x, w), O.conv2d(xd, wd, None), 2e-5, "y")
+    ref = O.conv2d(torch.relu(xd), wd, b1.double().cpu()) + b2.double().cpu()
+    _close(ops.conv2d_fwd(x, w, b1, b2, relu_in=True), ref, 2e-5, "y (relu_in, bias, bias2)")
+    out = prev.clone()
+    ops.conv2d_fwd(x, w, b1, out=out, accum=True)
+    _close(out, O.conv2d(xd, wd, b1.double().cpu()) + prev.double().cpu(), 2e-5, "y (accumulate)")
+    _close(ops.conv2d_fwd(x, w, b1, relu_out=True), torch.relu(O.conv2d(xd, wd, b1.double().cpu())), 2e-5, "y (relu_out)")
+    if not dgrad_too:
+        return
+    # data-grad: plain; ReLU mask; mask + accumulate
+    xr = xd.clone().requires_grad_(True)
+    O.conv2d(xr, wd, None).backward(dyd)
+    _close(ops.conv2d_bwd_data(dy, w, (H, W)), xr.grad, 2e-5, "dx")
+    _close(ops.conv2d_bwd_data(dy, w, (H, W), mask=x), xr.grad * (xd > 0), 2e-5, "dx (mask)")
+    acc = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    ref = xr.grad * (xd > 0) + acc.double().cpu()
+    ops.conv2d_bwd_data(dy, w, (H, W), mask=x, out=acc, accum=True)
+    _close(acc, ref, 2e-5, "dx (mask, accumulate)")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(128, 16, 80, 512, 512), (48, 8, 40, 1024, 1024), (16, 4, 20, 1024, 1024), (24, 8, 40, 512, 1024)])
+def test_agrees_with_the_direct_kernels_at_launch_geometry(dev, B, H, W, Cin, Cout):
+    """The same launch through both forms (SG_WINOGRAD on / off) at the headline batch and the 8-way shard batch: both are held to
+    2e-5 of the fp64 oracle elsewhere, so they may differ by twice that."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B + Cin)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    assert ops._wino_ok(Cin, Cout, 3, 3, True, H, W)
+    yw = ops.conv2d_fwd(x, w, b, relu_in=True)
+    dxw = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+    old = ops.USE_WINOGRAD
+    ops.USE_WINOGRAD = False
+    try:
+        yd = ops.conv2d_fwd(x, w, b, relu_in=True)
+        dxd = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+    finally:
+        ops.USE_WINOGRAD = old
+    _close(yw, yd, 4e-5, "y: Winograd vs direct")
+    _close(dxw, dxd, 4e-5, "dx: Winograd vs direct")
+
+
+def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
+    """sg_conv2d_fwd_wino / sg_conv2d_bwd_data_wino with a caller-provided workspace: bitwise the result of the three exported
+    steps the host path calls; a short workspace and an odd height are refused before anything is launched."""
+    ops = wino_everywhere
+    from scrabble_gan_amd._lib import lib
+    L = lib()
+    B, H, W, Cin, Cout = 4, 4, 20, 64, 128
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    nbytes = L.sg_wino_workspace_bytes(B, H, W, Cin, Cout)
+    T = B * (H // 2) * (W // 2)
+    assert nbytes == 4 * 16 * (-(-T // 256) * 256) * (Cin + Cout)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    s = ops._stream()
+    y = torch.empty(B, H, W, Cout, device=dev)
+    u = ops.packed_filter(w, "wino_fwd")
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, 1, ws.data_ptr(), nbytes, s) == 0
+    assert torch.equal(y, ops.conv2d_fwd(x, w, b, relu_in=True))
+    dx = torch.empty(B, H, W, Cin, device=dev)
+    ub = ops.packed_filter(w, "wino_bwd")
+    assert L.sg_conv2d_bwd_data_wino(dy.data_ptr(), ub.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == 0
+    assert torch.equal(dx, ops.conv2d_bwd_data(dy, w, (H, W), mask=x))
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes - 1, s) == -1
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, 3, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == -3
+    assert L.sg_wino_workspace_bytes(B, 3, W, Cin, Cout) == 0
+
+
+def test_filter_transform_vs_definition(dev):
+    """U = G g G^T per channel pair, forward layout [16][Cout][Cin] and mirrored-tap data-grad layout [16][Cin][Cout]."""
+    from scrabble_gan_amd import ops
+    Cin, Cout = 32, 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    wd = w.double().cpu()
+    uf = torch.einsum("ia,abck,jb->ijkc", G, wd, G).reshape(16, Cout * Cin)
+    ub = torch.einsum("ia,abck,jb->ijck", G, wd.flip(0, 1), G).reshape(16, Cin * Cout)
+    assert (ops.packed_filter(w, "wino_fwd").double().cpu() - uf).abs().max().item() < 1e-6
+    assert (ops.packed_filter(w, "wino_bwd").double().cpu() - ub).abs().max().item() < 1e-6
+
+
+def test_sample_results_do_not_depend_on_the_batch_in_deterministic_mode(dev):
+    """Deterministic mode (no reduction split): a sample's result is bitwise the same alone and inside a batch, run to run."""
+    from scrabble_gan_amd import ops
+    H, W, C = 4, 20, 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(40, H, W, C, device=dev, generator=g)
+    w = torch.randn(3, 3, C, C, device=dev, generator=g) / 96.0
+    ops.set_deterministic(True)
+    try:
+        a = ops.conv2d_fwd(x, w, relu_in=True)
+        b = ops.conv2d_fwd(x, w, relu_in=True)
+        c = ops.conv2d_fwd(x[:3].contiguous(), w, relu_in=True)
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(a, b) and torch.equal(a[:3], c)

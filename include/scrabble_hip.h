@@ -97,6 +97,17 @@ int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, co
                        int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
 int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx,
                             int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+/*      Weight gradient in the same domain (contract of sg_conv2d_bwd_weight, resnet_ops.py:65,98,103 under the tape: dw += ,
+ *      db += when non-null, sample_scale [B] nullable, SG_RELU_IN on x): dU[f] = V[f]^T Qt[f] over the tiles with
+ *      Qt = A dy A^T (sg_wino_grad_input: rows scaled by sample_scale[b], db += their column sums), then dw += G^T dU G
+ *      (sg_wino_filter_grad).  sg_wino_wgrad_gemm overwrites dU [16][Cin][Cout]; partial sums of the tile chunks meet through
+ *      float atomics (one chunk in deterministic mode).  Workspace: sg_wino_wgrad_workspace_bytes = V | Qt | dU. */
+long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, void* stream);
+int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, void* stream);
+int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, void* stream);
+int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale,
+                              int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
  *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale

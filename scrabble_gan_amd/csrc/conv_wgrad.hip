@@ -41,7 +41,10 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   const int m_begin = chunk * p.mchunk;
   const int m_end = min(M, m_begin + p.mchunk);
   const int KT = (m_end - m_begin + BK - 1) / BK;
-  const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+  const bool grouped = p.p_plane > 0;                          // (uniform) conv_winograd.hip: tap t = independent product t
+  const int dy = grouped ? 0 : p.taps[t < SG_MAX_TAPS ? t : 0].dy, dx = grouped ? 0 : p.taps[t < SG_MAX_TAPS ? t : 0].dx;
+  const float* const p_base = p.p + (grouped ? (size_t)t * (size_t)p.p_plane : (size_t)0);
+  const float* const q_base = p.q + (grouped ? (size_t)t * (size_t)p.q_plane : (size_t)0);
   const bool relu_in = (p.flags & SG_RELU_IN) != 0;
 
   float4 p_reg[P_P], q_reg[Q_P];
@@ -55,8 +58,8 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   // contribute zero (padding tap, pixel past the chunk, channel past the edge) gets an out-of-range offset and
   // reads 0.0 -- no select after the load, so the registers are first touched by the LDS store three k-steps later.
   constexpr unsigned OOB = 0xFFFFFFE0u;
-  const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.p), 0, (int)p.p_bytes, 0x00020000);
-  const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.q), 0, (int)p.q_bytes, 0x00020000);
+  const auto rsrc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_base), 0, (int)p.p_bytes, 0x00020000);
+  const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q_base), 0, (int)p.q_bytes, 0x00020000);
   auto bload = [](decltype(rsrc_p) r, unsigned voff) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
     return *reinterpret_cast<const float4*>(&v);
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
   };
   const bool do_bias = p.dbias != nullptr && t == 0 && c0 == 0;     // one (tap, c-tile) column of workgroups sums dy
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QSCALE ? p.qscale : p.q), 0, QSCALE ? 4 * p.Bn : 0, 0x00020000);
+  const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(QSCALE ? p.qscale : q_base), 0, QSCALE ? 4 * p.Bn : 0, 0x00020000);
   unsigned vzero = 0;
   asm volatile("" : "+v"(vzero));                                 // opaque per-lane zero: keeps the factor load on the vector path
   int qs_b = m_begin / HW, qs_rem = m_begin - (m_begin / HW) * HW; // (QSCALE == 2) sample of the next k-tile
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(WM* WN * 64, OCC) void sg_wgrad_kernel(const SgWgra
     }
   }
 
-  float* dwt = p.dw + p.taps[t].w_off;
+  float* dwt = p.dw + (grouped ? (size_t)t * (size_t)p.Cp * (size_t)p.Cq : (size_t)p.taps[t < SG_MAX_TAPS ? t : 0].w_off);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -308,7 +311,8 @@ static int launch_wgrad_cfg(SgWgradArgs a, hipStream_t s) {
 
 int sg_launch_wgrad(const SgWgradArgs& a_in, hipStream_t s) {
   SgWgradArgs a = a_in;
-  if ((a.Cp & 3) || (a.Cq & 3) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_ARG;
+  if ((a.Cp & 3) || (a.Cq & 3) || a.ntaps < 1 || a.ntaps > (a.p_plane > 0 ? SG_MAX_GROUPS : SG_MAX_TAPS)) return SG_ERR_ARG;
+  if (a.p_plane > 0 && (a.qscale || a.dbias || a.q_plane <= 0)) return SG_ERR_ARG;
   const long p_elems = (long)a.Bn * a.Hp * a.Wp * a.Cp, q_elems = (long)a.Bn * a.Hq * a.Wq * a.Cq;
   if (p_elems >= (1L << 30) - 8 || q_elems >= (1L << 30) - 8) return SG_ERR_ARG;   // 32-bit byte offsets (buffer loads)
   a.p_bytes = (unsigned)(4 * p_elems);

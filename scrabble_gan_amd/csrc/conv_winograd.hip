@@ -151,6 +151,97 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mt, 
   }
 }
 
+// ---- weight gradient.  With M = sum_c U (.) V and Y = A^T M A:  dM = A dY A^T (4x4 from the tile's 2x2 output gradients),
+//      dU[f][c][n] = sum_tiles V[f][t][c] dM[f][t][n] (sixteen [K x T] x [T x N] products: the fp32 weight-grad kernel of
+//      conv_wgrad.hip in its grouped form), dW = G^T dU G.
+// gradient transform: dy [B,H,W,N] -> Qt [16][Tp][N], rows scaled by sample_scale[b] (nullable); db (nullable) += column sums of
+// the scaled dy.  One thread = one tile x four channels; A = [1 0; 1 1; 1 -1; 0 -1].
+__global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
+                                                 float* __restrict__ db, int H, int W, int N, long T, long Tp) {
+  __shared__ float4 red[256];
+  const int N4 = N >> 2, H2 = H >> 1, W2 = W >> 1;
+  const long items = T * N4;
+  const size_t plane = (size_t)Tp * N;
+  // a thread keeps ONE channel group over its whole grid-stride loop when the stride is a multiple of N4 (every power-of-two
+  // channel count): threads tid, tid + N4, ... of a block then share it; otherwise the column sums go out per item
+  const bool fixed_col = ((long)gridDim.x * 256) % N4 == 0;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / N4;
+    const int n = (int)(it - t * N4) * 4;
+    const int tx = (int)(t % W2);
+    const long r = t / W2;
+    const int ty = (int)(r % H2);
+    const long b = r / H2;
+    const float sc = sample_scale ? sample_scale[b] : 1.f;
+    float4 d[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * H + 2 * ty + i) * W + 2 * tx + j) * N + n);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        d[i][j] = v;
+      }
+    if (db) {
+      const float4 s4 = f4_add(f4_add(d[0][0], d[0][1]), f4_add(d[1][0], d[1][1]));
+      if (fixed_col) bsum = f4_add(bsum, s4);
+      else { atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w); }
+    }
+    float4 rr[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rr[0][j] = d[0][j];
+      rr[1][j] = f4_add(d[0][j], d[1][j]);
+      rr[2][j] = f4_sub(d[0][j], d[1][j]);
+      rr[3][j] = make_float4(-d[1][j].x, -d[1][j].y, -d[1][j].z, -d[1][j].w);
+    }
+    float* out = Qt + (size_t)t * N + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 0) * plane) = rr[i][0];
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 1) * plane) = f4_add(rr[i][0], rr[i][1]);
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 2) * plane) = f4_sub(rr[i][0], rr[i][1]);
+      *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 3) * plane) = make_float4(-rr[i][1].x, -rr[i][1].y, -rr[i][1].z, -rr[i][1].w);
+    }
+  }
+  if (db && fixed_col) {          // (block-uniform) threads tid, tid + N4, ... of the block hold the same channel group when N4 < 256
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    const int per = N4 < 256 ? N4 : 256;
+    if ((int)threadIdx.x < per) {
+      float4 s4 = red[threadIdx.x];
+      for (int k = threadIdx.x + per; k < 256; k += per) s4 = f4_add(s4, red[k]);
+      const int n = (int)((((long)blockIdx.x * 256 + threadIdx.x) % N4) * 4);
+      atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w);
+    }
+  }
+}
+
+// filter-gradient transform: dw [3][3][K][N] += G^T dU G, dU [16][K][N]
+__global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ dU, float* __restrict__ dw, long KN) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < KN; e += (long)gridDim.x * 256) {
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[i][j] = dU[(size_t)(i * 4 + j) * KN + e];
+    float h[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+      h[1][j] = 0.5f * (u[1][j] - u[2][j]);
+      h[2][j] = u[3][j] + 0.5f * (u[1][j] + u[2][j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      dw[(size_t)(a * 3 + 0) * KN + e] += h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+      dw[(size_t)(a * 3 + 1) * KN + e] += 0.5f * (h[a][1] - h[a][2]);
+      dw[(size_t)(a * 3 + 2) * KN + e] += h[a][3] + 0.5f * (h[a][1] + h[a][2]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // C-ABI (include/scrabble_hip.h)
 // ------------------------------------------------------------------------------------------
@@ -235,4 +326,62 @@ extern "C" int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, cons
                                        int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
   if (flags & (SG_RELU_IN | SG_RELU_OUT)) return SG_ERR_ARG;
   return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- weight gradient: workspace = V [16][Tp][Cin] | Qt [16][Tp][Cout] | dU [16][Cin][Cout]
+extern "C" long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0) return 0;
+  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  return (long)sizeof(float) * WINO_F * (Tp * ((long)Cin + Cout) + (long)Cin * Cout);
+}
+
+extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, void* stream) {
+  if (!dy || !Qt) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, 32, 64) || (N & 3) || N <= 0) return SG_ERR_UNSUPPORTED;
+  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  SG_KERNEL(k_wino_dy, dim3(sg_grid_for(T * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  return sg_launch_status();
+}
+
+// dU [16][K][N] = sum over the T tiles of V[f]^T Qt[f] (dU is overwritten)
+extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, void* stream) {
+  if (!V || !Qt || !dU) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, 32, 64) || (K & 3) || (N & 3) || K <= 0 || N <= 0) return SG_ERR_UNSUPPORTED;
+  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  if (T >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dU, 0, sizeof(float) * (size_t)WINO_F * K * N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  SgWgradArgs a{};
+  a.p = V; a.q = Qt; a.dw = dU;
+  a.Bn = (int)T; a.Hp = 1; a.Wp = 1; a.Cp = K; a.p_sy = 1; a.p_sx = 1;
+  a.Hq = 1; a.Wq = 1; a.Cq = N; a.q_sy = 1; a.q_sx = 1; a.Hg = 1; a.Wg = 1;
+  a.ntaps = WINO_F; a.flags = 0;
+  a.p_plane = Tp * K;
+  a.q_plane = Tp * N;
+  return sg_launch_wgrad(a, s);
+}
+
+extern "C" int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, void* stream) {
+  if (!dU || !dw || K <= 0 || N <= 0) return SG_ERR_ARG;
+  const long KN = (long)K * N;
+  SG_KERNEL(k_wino_dw, dim3(sg_grid_for(KN, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, KN);
+  return sg_launch_status();
+}
+
+extern "C" int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale, int B, int H, int W,
+                                         int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
+  if (!x || !dy || !dw || !workspace) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, Cin, 64) || (Cout & 3)) return SG_ERR_UNSUPPORTED;
+  if (workspace_bytes < sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return SG_ERR_ARG;
+  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  float* V = reinterpret_cast<float*>(workspace);
+  float* Qt = V + (size_t)WINO_F * Tp * Cin;
+  float* dU = Qt + (size_t)WINO_F * Tp * Cout;
+  int rc = sg_wino_input(x, V, B, H, W, Cin, (flags & SG_RELU_IN) != 0, stream);
+  if (rc != SG_OK) return rc;
+  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, B, H, W, Cout, stream);
+  if (rc != SG_OK) return rc;
+  rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, stream);
+  if (rc != SG_OK) return rc;
+  return sg_wino_filter_grad(dU, dw, Cin, Cout, stream);
 }

@@ -743,6 +743,38 @@ def _wino_conv(a, u, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
         call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags, s)
 
 
+def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
+    """Weight gradient in the Winograd domain: sixteen [Cin x tiles] x [tiles x Cout] products.  Not in deterministic mode (one
+    pixel chunk per product would leave 256 workgroups for the whole launch: the direct kernel's single-chunk form is used)."""
+    return (USE_WINOGRAD and CONV_DTYPE == "f32" and not DETERMINISTIC and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
+            and Cin % 32 == 0 and Cout % 64 == 0 and min(Cin, Cout) >= WINO_MIN_N and Cin * Cout >= WINO_MIN_K * WINO_MIN_N)
+
+
+def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    T = B * (H // 2) * (W // 2)
+    Tp = -(-T // 256) * 256
+    ws = _wino_workspace(lib().sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout), x)
+    V = ws.data_ptr()
+    Qt = V + 4 * 16 * Tp * Cin
+    dU = Qt + 4 * 16 * Tp * Cout
+    s = _stream()
+    with _hbm("wino_transform", x, dy):
+        if PROFILER is not None and PROFILER.wants("wino_transform"):
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * (Cin + Cout)
+        call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), s)
+        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), B, H, W, Cout, s)
+    with _timed("wgrad", 2.0 * 16 * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
+        if PROFILER is not None and PROFILER.wants("wgrad"):
+            PROFILER.nbytes["wgrad"] = PROFILER.nbytes.get("wgrad", 0.0) + 4.0 * 16 * (T * (Cin + Cout) + Cin * Cout)
+        call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, s)
+    with _hbm("wino_transform", dw, dw):
+        if PROFILER is not None and PROFILER.wants("wino_transform"):
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * Cin * Cout
+        call("sg_wino_filter_grad", dU, _p(dw), Cin, Cout, s)
+
+
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
     return USE_V2 and _low() and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
 
@@ -870,6 +902,9 @@ def conv2d_bwd_weight(x, dy, dw, same=True, relu_in=False, db=None, sample_scale
     B, H, W, Cin = x.shape
     kh, kw, wc, Cout = dw.shape
     assert wc == Cin and dy.shape[3] == Cout
+    if _wino_wgrad_ok(Cin, Cout, kh, kw, same, H, W):
+        _wino_wgrad(x, dy, dw, db, sample_scale, relu_in)
+        return
     if _fp8_wgrad_ok(Cin, Cout, kh, kw, same):
         # config c5: e4m3 activations (the copy the forward launch read: ReLU folded into the conversion) x e5m2 gradients
         x8, ax = fp8_of(x, relu_in)

@@ -6,7 +6,6 @@ Tolerances (max |got - ref| <= tol * max |ref|): 2e-5 against the fp64 oracle, t
 (tests/test_fullsize_gpu.py); the measured error is printed -- the transforms add <= 4 terms per dimension, so the Winograd
 form's rounding error is a small multiple of the direct form's.  Launch-geometry rows of tests/test_fullsize_gpu.py (f32 mode) and
 the whole-network / train_step tests run through this path too (ops._wino_ok)."""
-import ctypes
 import math
 
 import pytest
@@ -75,10 +74,32 @@ def test_forward_and_data_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cou
     _close(acc, ref, 2e-5, "dx (mask, accumulate)")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,scaled", [(3, 2, 4, 64, 64, False), (5, 4, 10, 96, 128, True), (2, 8, 40, 128, 64, True),
+                                                   (7, 6, 6, 64, 192, False), (33, 4, 20, 256, 256, True), (16, 8, 40, 512, 1024, True)])
+def test_weight_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cout, scaled):
+    """dW += and the bias gradient of the same sweep, with the per-sample factors of the shared backward sweep (`scaled`) and the
+    operand ReLU: 1e-4 of max |dW| against the fp64 oracle (the bound of the direct weight-grad kernels)."""
+    ops = wino_everywhere
+    assert ops._wino_wgrad_ok(Cin, Cout, 3, 3, True, H, W)
+    g = torch.Generator(device=dev).manual_seed(B * 100 + H + Cin)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    sc = (torch.rand(B, device=dev, generator=g) * 2 - 0.5) if scaled else None
+    dw0 = torch.randn(3, 3, Cin, Cout, device=dev, generator=g)
+    db0 = torch.randn(Cout, device=dev, generator=g)
+    dw, db = dw0.clone(), db0.clone()
+    ops.conv2d_bwd_weight(x, dy, dw, relu_in=True, db=db, sample_scale=sc)
+    dys = (dy if sc is None else dy * sc.view(B, 1, 1, 1)).double().cpu()
+    wz = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    O.conv2d(torch.relu(x.double().cpu()), wz, None).backward(dys)
+    _close(dw - dw0, wz.grad, 1e-4, "dW")
+    _close(db - db0, dys.sum((0, 1, 2)), 1e-4, "db")
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(128, 16, 80, 512, 512), (48, 8, 40, 1024, 1024), (16, 4, 20, 1024, 1024), (24, 8, 40, 512, 1024)])
 def test_agrees_with_the_direct_kernels_at_launch_geometry(dev, B, H, W, Cin, Cout):
     """The same launch through both forms (SG_WINOGRAD on / off) at the headline batch and the 8-way shard batch: both are held to
-    2e-5 of the fp64 oracle elsewhere, so they may differ by twice that."""
+    2e-5 (dW, db: 1e-4) of the fp64 oracle elsewhere, so they may differ by twice that."""
     from scrabble_gan_amd import ops
     g = torch.Generator(device=dev).manual_seed(B + Cin)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g)
@@ -86,17 +107,24 @@ def test_agrees_with_the_direct_kernels_at_launch_geometry(dev, B, H, W, Cin, Co
     b = torch.randn(Cout, device=dev, generator=g)
     dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
     assert ops._wino_ok(Cin, Cout, 3, 3, True, H, W)
+    sc = torch.rand(B, device=dev, generator=g) + 0.5
     yw = ops.conv2d_fwd(x, w, b, relu_in=True)
     dxw = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+    dww, dbw = torch.zeros_like(w), torch.zeros_like(b)
+    ops.conv2d_bwd_weight(x, dy, dww, relu_in=True, db=dbw, sample_scale=sc)
     old = ops.USE_WINOGRAD
     ops.USE_WINOGRAD = False
     try:
         yd = ops.conv2d_fwd(x, w, b, relu_in=True)
         dxd = ops.conv2d_bwd_data(dy, w, (H, W), mask=x)
+        dwd, dbd = torch.zeros_like(w), torch.zeros_like(b)
+        ops.conv2d_bwd_weight(x, dy, dwd, relu_in=True, db=dbd, sample_scale=sc)
     finally:
         ops.USE_WINOGRAD = old
     _close(yw, yd, 4e-5, "y: Winograd vs direct")
     _close(dxw, dxd, 4e-5, "dx: Winograd vs direct")
+    _close(dww, dwd, 2e-4, "dW: Winograd vs direct")
+    _close(dbw, dbd, 2e-4, "db: Winograd vs direct")
 
 
 def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
@@ -124,6 +152,16 @@ def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
     ub = ops.packed_filter(w, "wino_bwd")
     assert L.sg_conv2d_bwd_data_wino(dy.data_ptr(), ub.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == 0
     assert torch.equal(dx, ops.conv2d_bwd_data(dy, w, (H, W), mask=x))
+    nb2 = L.sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)
+    assert nb2 == nbytes + 4 * 16 * Cin * Cout
+    ws2 = torch.empty(nb2, device=dev, dtype=torch.uint8)
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, H, W, Cin, Cout, 1, ws2.data_ptr(), nb2, s) == 0
+    dw_h, db_h = torch.zeros_like(w), torch.zeros_like(b)
+    ops.conv2d_bwd_weight(x, dy, dw_h, relu_in=True, db=db_h)
+    _close(dw, dw_h, 1e-5, "dW: C entry vs host path (float-atomic order only)")
+    _close(db, db_h, 1e-5, "db: C entry vs host path")
+    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, None, B, H, W, Cin, Cout, 1, ws2.data_ptr(), nb2 - 1, s) == -1
     assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes - 1, s) == -1
     assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, 3, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == -3
     assert L.sg_wino_workspace_bytes(B, 3, W, Cin, Cout) == 0

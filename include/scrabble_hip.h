@@ -74,7 +74,7 @@ int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, fl
                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
 /* ---- Winograd-domain fp32 3x3 convolutions, F(2x2, 3x3) (round 3; conv_winograd.hip): stride-1 SAME 3x3 convolutions with
- *      H, W even, reduction channels % 32 == 0 and output channels % 64 == 0 as sixteen [tiles x K] x [K x N] products
+ *      H, W even, reduction channels % 32 == 0 and output channels % 128 == 0 as sixteen [tiles x K] x [K x N] products
  *      (16 / 36 of the direct multiplies) between an input and an output transform.  Same contracts, flags and results as
  *      sg_conv2d_fwd / sg_conv2d_bwd_data (resnet_ops.py:65,98,103) up to fp32 rounding (the transforms add <= 4 terms per
  *      dimension); SG_ERR_UNSUPPORTED for other shapes (caller: the direct entry points).
@@ -82,12 +82,13 @@ int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, fl
  *            forward : w_nk = sg_transpose_filter(w, 9, K = Cin, N = Cout) ([tap][Cout][Cin]), flip = 0;
  *            data-grad: w_nk = w [3,3,Cin,Cout] itself (N = Cin, K = Cout),              flip = 1 (taps mirrored);
  *        workspace: sg_wino_workspace_bytes(B, H, W, Cin, Cout) bytes of device memory, caller-provided, contents scratch:
- *            V [16][Tp][K] followed by Mt [16][Tp][N], Tp = B H/2 W/2 rounded up to 256.
+ *            V [16][Tp][K] followed by Mt [16][Tp][N], Tp = sg_wino_plane_rows(B, H, W) = B H/2 W/2 rounded up to 128.
  *      The three steps are also exported one by one (the host side times the HBM-bound transforms apart from the
  *      matrix-bound product): sg_wino_input (x [B,H,W,C] -> V, relu != 0 applies max(.,0) to x), sg_wino_gemm
  *      (Mt[f] = V[f] U[f]^T for the 16 frequencies in one grouped launch), sg_wino_output (Mt -> y with bias + bias2, ReLU
  *      mask, SG_ACCUM, SG_RELU_OUT). */
 long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+long sg_wino_plane_rows(int B, int H, int W);
 int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, void* stream);
 int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream);
 int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask,

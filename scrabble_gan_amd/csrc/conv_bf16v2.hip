@@ -791,7 +791,7 @@ int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_r
   SgIgemm2Args a = a_in;
   if ((a.Ca % (128 / es)) || (a.N % 64) || a.ntaps < 1 || a.ntaps > SG_MAX_TAPS) return SG_ERR_UNSUPPORTED;
   if (es == 1 && ((a.N % 256) || !a.amax_a || !a.amax_w)) return SG_ERR_UNSUPPORTED;
-  if (a.group_rows && ((a.group_rows % SG2_BM) || a.ntaps != 1 || a.Ha != 1 || a.Wa != 1 || a.Hg != 1 || a.Wg != 1 || a.Ho != 1 || a.Wo != 1 || a.out16 ||
+  if (a.group_rows && ((a.group_rows % 128) || a.ntaps != 1 || a.Ha != 1 || a.Wa != 1 || a.Hg != 1 || a.Wg != 1 || a.Ho != 1 || a.Wo != 1 || a.out16 ||
                        a.mask || a.mask16 || a.amax_out || (long)a.Bn % a.group_rows))
     return SG_ERR_ARG;      // (grouped launches: plain [rows, Ca] x [N, Ca]^T products per group)
   const long a_bytes = (long)es * (a.group_rows ? a.group_rows : a.Bn) * a.Ha * a.Wa * a.Ca;
@@ -826,6 +826,9 @@ int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_r
     return sg2_launch_bn<64, 1>(a, s, twin_rows_done);
   }
   if (es == 4) {
+    // grouped launches (Winograd-domain products): 128 x 128 tiles, two workgroups per CU -- level with the 256-row tiles on the
+    // large launches (profiles/r03_probe_winograd.txt: 10.49 vs 10.58 ms, 8.67 vs 8.65 ms) and half the plane padding on the small ones
+    if (a.group_rows) return a.N % 128 == 0 ? sg2_launch_bn<128, 4, 128>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;
     if (bn == 256) return sg2_launch_bn<256, 4>(a, s, twin_rows_done);
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);
     return sg2_launch_bn<64, 4>(a, s, twin_rows_done);

@@ -16,13 +16,19 @@
 // Numerics: exact fp32 products and fp32 accumulation like the direct kernels; the transforms add at most four terms per
 // dimension and the filter transform scales by 1/2 and 1/4 (exact), so the error grows by a small constant factor over the
 // direct form (tests/test_winograd_gpu.py states the bound against the fp64 oracle).
-// Tiles: t = (b * H/2 + ty) * W/2 + tx, T = B H/2 W/2 of them, planes padded to Tp = T rounded up to 256 rows (the GEMM
-// kernel's tile height: a tile never straddles two frequencies); the pad rows are never written nor read back.
+// Tiles: t = (b * H/2 + ty) * W/2 + tx, T = B H/2 W/2 of them, planes padded to Tp = T rounded up to 128 rows (the tile height of
+// the grouped product: a tile never straddles two frequencies; 128 rather than 256 rows because the 8-way shard batch has
+// T = 320 on the 4x20 layers); the pad rows are never written nor read back.
 #include "sg_conv2.h"
 
 #define WINO_F 16
 
-static inline long wino_tp(long T) { return (T + 255) / 256 * 256; }
+static inline long wino_tp(long T) { return (T + 127) / 128 * 128; }      // (the grouped product runs on 128-row tiles)
+
+extern "C" long sg_wino_plane_rows(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+  return wino_tp((long)B * (H / 2) * (W / 2));
+}
 
 // ---- filter transform: in [3][3][N][K] (fp32) -> U [16][N][K];  flip != 0 reads tap (2 - a, 2 - b) for (a, b)
 __global__ __launch_bounds__(256) void k_wino_filter(const float* __restrict__ in, float* __restrict__ U, long NK, int flip) {
@@ -275,7 +281,7 @@ extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int 
 
 extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream) {
   if (!V || !u || !Mt) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N)) return SG_ERR_UNSUPPORTED;
+  if (!wino_shape_ok(B, H, W, K, N) || (N % 128)) return SG_ERR_UNSUPPORTED;
   const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
   if (WINO_F * Tp >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
   SgIgemm2Args g{};
@@ -305,7 +311,7 @@ extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, cons
 static int wino_conv(const float* a, const float* u, const float* bias, const float* bias2, const float* mask, float* out, int B, int H, int W,
                      int K, int N, int flags, void* workspace, long workspace_bytes, hipStream_t s) {
   if (!a || !u || !out || !workspace) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
+  if (!wino_shape_ok(B, H, W, K, N) || (N % 128) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
   const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
   if (workspace_bytes < (long)sizeof(float) * WINO_F * Tp * ((long)K + N)) return SG_ERR_ARG;
   float* V = reinterpret_cast<float*>(workspace);

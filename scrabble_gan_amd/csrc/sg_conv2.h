@@ -26,7 +26,7 @@ struct SgIgemm2Args {
   int ntaps, flags;
   int full_tiles, tail_split, n_tiles_total;
   // grouped launch (conv_winograd.hip): rows [g * group_rows, (g + 1) * group_rows) of the base grid form group g, whose activation
-  // operand starts a_group_bytes and whose filter starts w_group_bytes behind group g - 1's (group_rows % 256 == 0: a tile never
+  // operand starts a_group_bytes and whose filter starts w_group_bytes behind group g - 1's (group_rows % 128 == 0, 128-row tiles: a tile never
   // straddles two groups; offsets inside a group stay 32-bit).  group_rows = 0: one group.
   int group_rows;
   long a_group_bytes, w_group_bytes;

@@ -697,14 +697,16 @@ def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool, pixels: int) -> bool
 
 # ---- Winograd-domain fp32 3x3 convolutions (conv_winograd.hip) --------------------------------------------------------
 USE_WINOGRAD = _os.environ.get("SG_WINOGRAD", "1") == "1"
-WINO_MIN_K = int(_os.environ.get("SG_WINO_MIN_K", "512"))     # reduction channels from which the 16 / 36 product count pays for the
-WINO_MIN_N = int(_os.environ.get("SG_WINO_MIN_N", "256"))     # two transform sweeps (tests set both to 32 / 64)
+# Where the 16 / 36 product count pays for the transform sweeps (profiles/r03_probe_winograd.txt, direct / Winograd time per launch):
+# 1.6-2.0x over >= 512 channels, 1.3-1.5x at 256, 1.1-1.3x at 128 -> 256 (R.conv3), 0.9x at 128 -> 128 and below.
+WINO_MIN_C = int(_os.environ.get("SG_WINO_MIN_C", "128"))        # both channel counts at least this ...
+WINO_MIN_KN = int(_os.environ.get("SG_WINO_MIN_KN", "32768"))    # ... and their product at least this (tests: 32 / 0)
 _WINO_WS = {}              # raw stream handle -> scratch buffer (V and Mt of the launch in flight on that stream)
 
 
 def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
     return (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
-            and K % 32 == 0 and N % 64 == 0 and K >= WINO_MIN_K and N >= WINO_MIN_N)
+            and K % 32 == 0 and N % 128 == 0 and min(K, N) >= WINO_MIN_C and K * N >= WINO_MIN_KN)
 
 
 def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -724,7 +726,7 @@ def _wino_conv(a, u, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
     """out [B,H,W,N] = conv3x3_same(a [B,H,W,K]) through input transform -> 16 grouped products -> output transform."""
     B, H, W, _ = a.shape
     T = B * (H // 2) * (W // 2)
-    Tp = -(-T // 256) * 256
+    Tp = lib().sg_wino_plane_rows(B, H, W)
     ws = _wino_workspace(lib().sg_wino_workspace_bytes(B, H, W, K, N), a)
     V = ws.data_ptr()
     Mt = V + 4 * 16 * Tp * K
@@ -747,14 +749,14 @@ def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W:
     """Weight gradient in the Winograd domain: sixteen [Cin x tiles] x [tiles x Cout] products.  Not in deterministic mode (one
     pixel chunk per product would leave 256 workgroups for the whole launch: the direct kernel's single-chunk form is used)."""
     return (USE_WINOGRAD and CONV_DTYPE == "f32" and not DETERMINISTIC and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
-            and Cin % 32 == 0 and Cout % 64 == 0 and min(Cin, Cout) >= WINO_MIN_N and Cin * Cout >= WINO_MIN_K * WINO_MIN_N)
+            and Cin % 32 == 0 and Cout % 64 == 0 and min(Cin, Cout) >= WINO_MIN_C and Cin * Cout >= WINO_MIN_KN)
 
 
 def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     T = B * (H // 2) * (W // 2)
-    Tp = -(-T // 256) * 256
+    Tp = lib().sg_wino_plane_rows(B, H, W)
     ws = _wino_workspace(lib().sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout), x)
     V = ws.data_ptr()
     Qt = V + 4 * 16 * Tp * Cin

@@ -1,7 +1,8 @@
 """Winograd-domain fp32 3x3 convolutions (scrabble_gan_amd/csrc/conv_winograd.hip; round 3) against the fp64 oracle.
 
 The path replaces the direct implicit-GEMM launch of the stride-1 SAME 3x3 convolutions over >= 512 reduction channels in fp32
-mode (resnet_ops.py:65,98,103 of the reference: the ResNet blocks' convolutions) -- same contract, 16 / 36 of the multiplies.
+mode -- and, with smaller gains, those down to 128 channels (ops._wino_ok) -- (resnet_ops.py:65,98,103 of the reference: the ResNet
+blocks' convolutions) -- same contract, 16 / 36 of the multiplies.
 Tolerances (max |got - ref| <= tol * max |ref|): 2e-5 against the fp64 oracle, the bound the direct fp32 kernels are held to
 (tests/test_fullsize_gpu.py); the measured error is printed -- the transforms add <= 4 terms per dimension, so the Winograd
 form's rounding error is a small multiple of the direct form's.  Launch-geometry rows of tests/test_fullsize_gpu.py (f32 mode) and
@@ -18,12 +19,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def wino_everywhere():
-    """Every eligible shape (K % 32 == 0, N % 64 == 0, even H and W) through the Winograd path."""
+    """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path."""
     from scrabble_gan_amd import ops
-    old = (ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD)
-    ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD = 32, 64, True
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD = 32, 0, True
     yield ops
-    ops.WINO_MIN_K, ops.WINO_MIN_N, ops.USE_WINOGRAD = old
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD = old
 
 
 def _close(got, ref, tol, name):
@@ -34,17 +35,17 @@ def _close(got, ref, tol, name):
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
 
 
-# B, H, W, Cin, Cout: one tile per sample; tile counts below / not a multiple of the 256-row plane padding; odd batches; the
-# recognizer-like wide rows; Cin != Cout both ways
-SMALL = [(1, 2, 2, 32, 64), (3, 2, 4, 64, 64), (5, 4, 10, 96, 128), (2, 8, 40, 128, 64), (7, 6, 6, 32, 192), (2, 16, 80, 64, 128),
-         (33, 4, 20, 256, 256)]
+# B, H, W, Cin, Cout: one tile per sample; tile counts below / not a multiple of the 128-row plane padding; odd batches; the
+# recognizer-like wide rows; Cin != Cout both ways (the data-grad runs when Cin % 128 == 0 too)
+SMALL = [(1, 2, 2, 32, 128), (3, 2, 4, 128, 128), (5, 4, 10, 96, 128), (2, 8, 40, 256, 128), (7, 6, 6, 32, 384), (2, 16, 80, 64, 128),
+         (33, 4, 20, 256, 256), (16, 4, 20, 128, 256)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SMALL)
 def test_forward_and_data_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cout):
     ops = wino_everywhere
     assert ops._wino_ok(Cin, Cout, 3, 3, True, H, W)
-    dgrad_too = ops._wino_ok(Cout, Cin, 3, 3, True, H, W)      # (the data-grad's output channels are Cin: % 64)
+    dgrad_too = ops._wino_ok(Cout, Cin, 3, 3, True, H, W)      # (the data-grad's output channels are Cin: % 128)
     g = torch.Generator(device=dev).manual_seed(B * 1000 + H * W + Cin)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g)
     w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
@@ -141,7 +142,7 @@ def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
     dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
     nbytes = L.sg_wino_workspace_bytes(B, H, W, Cin, Cout)
     T = B * (H // 2) * (W // 2)
-    assert nbytes == 4 * 16 * (-(-T // 256) * 256) * (Cin + Cout)
+    assert L.sg_wino_plane_rows(B, H, W) == -(-T // 128) * 128 and nbytes == 4 * 16 * (-(-T // 128) * 128) * (Cin + Cout)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     s = ops._stream()
     y = torch.empty(B, H, W, Cout, device=dev)

@@ -300,7 +300,8 @@ def roofline_of(res, conv_dtype, world):
         traffic, traffic_src = committed_traffic("igemm", conv_dtype, res["B"] // world)
     except Exception:  # noqa: BLE001
         traffic, traffic_src = None, None
-    kernel_name = {"f32": "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)",
+    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the sixteen grouped Winograd-domain products of a 3x3 conv fwd / data-grad, fp32 MFMA "
+                          "32x32x2, executed FLOPs) + sg_igemm_kernel / sg_igemm_bf16v2_kernel<BN, 4, RELU> for the direct launches (1x1, 64-channel, strided)",
                    "bf16": "sg_igemm_bf16v2_kernel<BN, 2, RELU> / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; <= 32-filter convs stay fp32)",
                    "fp8": "sg_igemm_bf16v2_kernel<256, 1, false> (conv fwd + data-grad of the >= 128-channel layers, v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 operands)"}[conv_dtype]
     out["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_of(dom), "unit": "TFLOP/s",
@@ -438,8 +439,13 @@ def main():
                        "global_batch": B, "per_gpu_batch": B // world, "parallelism": "dp%d" % world},
             "host_enqueue_ms_per_step": res["host_enqueue"] / args.steps * 1e3,
             "step_algorithmic_tflops": FLOP_PER_IMAGE * value / 1e12 if (L == 10 and not args.bucketed) else None,      # reference-tape accounting
-            "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if (L == 10 and not args.bucketed) else None,  # what the kernels actually run
+            "step_executed_tflops": FLOP_PER_IMAGE_EXECUTED * value / 1e12 if (L == 10 and not args.bucketed) else None,  # direct form, shared sweeps counted once
         }
+        if args.conv_dtype == "f32":
+            line["flop_accounting"] = ("step_algorithmic_tflops / step_executed_tflops count DIRECT-form convolution FLOPs (the reference's tapes); in fp32 "
+                                       "mode the 3x3 convolutions over >= 128 channels run in the Winograd domain F(2x2,3x3) at 16/36 of that count "
+                                       "(conv_winograd.hip), so these rates may exceed the fp32 MFMA peak.  roofline.achieved and kernels.* count the "
+                                       "products the matrix cores EXECUTE (Winograd-domain products for those launches) over HIP-event time")
         line["config"]["hip_graph"] = bool(args.graph)
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True

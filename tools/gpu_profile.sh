@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile pass on the GPU box: kernel stats of the bench command (fp32 bs 128 = the headline, bs 16 = the 8-way
 # shard size, bf16 bs 256 = config c3), the separate PMC passes for the HBM-side traffic of the dominant conv kernels, and
-# SQ counters of the bf16 kernels on the 1024->1024 layer.  Usage: bash tools/gpu_profile.sh OUTDIR
+# SQ counters of the bf16 kernels on the 1024->1024 layer.  Usage: bash tools/gpu_profile.sh OUTDIR   (ONLY_F32=1: the fp32 passes alone)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/${1:-gpurun_out/prof}
@@ -12,10 +12,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats128 -o run -- py
 echo stats128 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats16 -o run -- python3 $B --steps 4 --warmup 2 --batch 16 > $O/stats16.log 2>&1
 echo stats16 done
+if [ -z "$ONLY_F32" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bf16 -o run -- python3 $B --steps 2 --warmup 1 --conv-dtype bf16 --batch 256 > $O/stats_bf16.log 2>&1
 echo stats_bf16 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp8 -o run -- python3 $B --steps 2 --warmup 1 --conv-dtype fp8 --batch 512 --balance > $O/stats_fp8.log 2>&1
 echo stats_fp8 done
+fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_fetch.log 2>&1
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_write.log 2>&1
@@ -25,7 +27,10 @@ python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_w
   --command "$CMD" --out $O/igemm_traffic_bs128.json > $O/traffic.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel sg_wgrad_kernel \
   --command "$CMD" --out $O/wgrad_traffic_bs128.json >> $O/traffic.log 2>&1
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel k_wino \
+  --command "$CMD" --out $O/wino_transform_traffic_bs128.json >> $O/traffic.log 2>&1
 rm -f $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv
+if [ -n "$ONLY_F32" ]; then echo profile pass done; exit 0; fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch16 -o run -- python3 $B --steps 1 --warmup 1 --conv-dtype bf16 --batch 256 > $O/pmc_fetch16.log 2>&1
 echo fetch bf16 done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write16 -o run -- python3 $B --steps 1 --warmup 1 --conv-dtype bf16 --batch 256 > $O/pmc_write16.log 2>&1

@@ -295,13 +295,16 @@ def roofline_of(res, conv_dtype, world):
             return PEAK_TF["fp8"]
         return PEAK_TF["f32"] if conv_dtype == "f32" else PEAK_TF["bf16"]
     dom = "igemm_fp8" if (conv_dtype == "fp8" and "igemm_fp8" in ks) else "igemm"
+    if conv_dtype == "f32" and ks.get("igemm_wino", {}).get("ms", 0.0) > ks.get("igemm", {}).get("ms", 0.0):
+        dom = "igemm_wino"      # the grouped Winograd-domain products (one kernel: sg_igemm_bf16v2_kernel<128, 4, false, 128>)
     ig = ks.get(dom, {"tflops": 0.0, "launches": 0, "ms": 0.0})
     try:
-        traffic, traffic_src = committed_traffic("igemm", conv_dtype, res["B"] // world)
+        traffic, traffic_src = committed_traffic(dom if dom == "igemm_wino" else "igemm", conv_dtype, res["B"] // world)
     except Exception:  # noqa: BLE001
         traffic, traffic_src = None, None
-    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the sixteen grouped Winograd-domain products of a 3x3 conv fwd / data-grad, fp32 MFMA "
-                          "32x32x2, executed FLOPs) + sg_igemm_kernel / sg_igemm_bf16v2_kernel<BN, 4, RELU> for the direct launches (1x1, 64-channel, strided)",
+    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the sixteen grouped Winograd-domain products of a 3x3 conv fwd / data-grad in one launch, "
+                          "fp32 MFMA 32x32x2, executed FLOPs; the direct launches -- 1x1, 64-channel, strided -- are the family 'igemm')" if dom == "igemm_wino" else
+                          "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)",
                    "bf16": "sg_igemm_bf16v2_kernel<BN, 2, RELU> / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; <= 32-filter convs stay fp32)",
                    "fp8": "sg_igemm_bf16v2_kernel<256, 1, false> (conv fwd + data-grad of the >= 128-channel layers, v_mfma_scale_f32_32x32x64_f8f6f4 on e4m3 operands)"}[conv_dtype]
     out["roofline"] = {"bound": "mfma", "achieved": ig["tflops"], "peak": peak_of(dom), "unit": "TFLOP/s",
@@ -315,12 +318,13 @@ def roofline_of(res, conv_dtype, world):
                           "launches_per_step": v["launches"] / timed_steps, "peak_tflops": peak_of(k) if not k.endswith("_thin") else None,
                           "frac_of_mfma_peak": round(v["tflops"] / peak_of(k), 4) if not k.endswith("_thin") else None}
                       for k, v in ks.items()}
-    if "wgrad" in out["kernels"]:
-        try:
-            wt, wsrc = committed_traffic("wgrad", conv_dtype, res["B"] // world)
-        except Exception:  # noqa: BLE001
-            wt, wsrc = None, None
-        out["kernels"]["wgrad"].update({"traffic": wt, "traffic_source": wsrc})
+    for fam in ("wgrad", "wgrad_wino", "igemm"):
+        if fam in out["kernels"] and fam != dom:
+            try:
+                wt, wsrc = committed_traffic(fam, conv_dtype, res["B"] // world)
+            except Exception:  # noqa: BLE001
+                wt, wsrc = None, None
+            out["kernels"][fam].update({"traffic": wt, "traffic_source": wsrc})
     if res["hs"] is not None:
         # memory-bound families: algorithmic bytes (every operand once + every result once) / HIP-event time,
         # against the 8 TB/s HBM3E peak of MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy reaches)

@@ -735,9 +735,9 @@ def _wino_conv(a, u, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * K
         call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), s)
-    with _timed("igemm", 2.0 * 16 * Tp * K * N, False, tag):
-        if PROFILER is not None and PROFILER.wants("igemm"):
-            PROFILER.nbytes["igemm"] = PROFILER.nbytes.get("igemm", 0.0) + 4.0 * 16 * (Tp * K + N * K + Tp * N)
+    with _timed("igemm_wino", 2.0 * 16 * Tp * K * N, False, tag):        # (executed FLOPs: the sixteen products, pad rows included)
+        if PROFILER is not None and PROFILER.wants("igemm_wino"):
+            PROFILER.nbytes["igemm_wino"] = PROFILER.nbytes.get("igemm_wino", 0.0) + 4.0 * 16 * (Tp * K + N * K + Tp * N)
         call("sg_wino_gemm", V, _p(u), Mt, B, H, W, K, N, s)
     with _hbm("wino_transform", out, mask, flops=0.0):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
@@ -767,9 +767,9 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * (Cin + Cout)
         call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), s)
         call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), B, H, W, Cout, s)
-    with _timed("wgrad", 2.0 * 16 * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
-        if PROFILER is not None and PROFILER.wants("wgrad"):
-            PROFILER.nbytes["wgrad"] = PROFILER.nbytes.get("wgrad", 0.0) + 4.0 * 16 * (T * (Cin + Cout) + Cin * Cout)
+    with _timed("wgrad_wino", 2.0 * 16 * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
+        if PROFILER is not None and PROFILER.wants("wgrad_wino"):
+            PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * 16 * (T * (Cin + Cout) + Cin * Cout)
         call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, s)
     with _hbm("wino_transform", dw, dw):
         if PROFILER is not None and PROFILER.wants("wino_transform"):

@@ -73,42 +73,44 @@ int sg_conv2d_fwd_v2(const float* x, const float* wt_fwd, const float* bias, con
 int sg_conv2d_bwd_data_v2(const float* dy, const float* w, const float* mask, float* dx,
                           int B, int H, int W, int Cin, int Cout, int kh, int kw, int pad_same, int flags, void* stream);
 
-/* ---- Winograd-domain fp32 3x3 convolutions, F(2x2, 3x3) (round 3; conv_winograd.hip): stride-1 SAME 3x3 convolutions with
- *      H, W even, reduction channels % 32 == 0 and output channels % 128 == 0 as sixteen [tiles x K] x [K x N] products
- *      (16 / 36 of the direct multiplies) between an input and an output transform.  Same contracts, flags and results as
- *      sg_conv2d_fwd / sg_conv2d_bwd_data (resnet_ops.py:65,98,103) up to fp32 rounding (the transforms add <= 4 terms per
- *      dimension); SG_ERR_UNSUPPORTED for other shapes (caller: the direct entry points).
- *        sg_wino_filter(w_nk [3][3][N][K], u [16][N][K], N, K, flip): transformed filter, once per optimizer step --
+/* ---- Winograd-domain fp32 3x3 convolutions (round 3; conv_winograd.hip): stride-1 SAME 3x3 convolutions with reduction
+ *      channels % 32 == 0 and output channels % 128 == 0 as (tile + 2)^2 independent [tiles x K] x [K x N] products between an
+ *      input and an output transform.  tile = 2: F(2x2, 3x3), 16 products per 2x2 outputs (16 / 36 of the direct multiplies),
+ *      H and W even;  tile = 4: F(4x4, 3x3), 36 products per 4x4 outputs (9 / 36), H % 4 == W % 4 == 0.  Same contracts, flags
+ *      and results as sg_conv2d_fwd / sg_conv2d_bwd_data (resnet_ops.py:65,98,103) up to fp32 rounding (tolerances in
+ *      tests/test_winograd_gpu.py); SG_ERR_UNSUPPORTED for other shapes (caller: the direct entry points).
+ *        sg_wino_filter(w_nk [3][3][N][K], u [(tile+2)^2][N][K], N, K, flip, tile): transformed filter, once per optimizer step --
  *            forward : w_nk = sg_transpose_filter(w, 9, K = Cin, N = Cout) ([tap][Cout][Cin]), flip = 0;
  *            data-grad: w_nk = w [3,3,Cin,Cout] itself (N = Cin, K = Cout),              flip = 1 (taps mirrored);
- *        workspace: sg_wino_workspace_bytes(B, H, W, Cin, Cout) bytes of device memory, caller-provided, contents scratch:
- *            V [16][Tp][K] followed by Mt [16][Tp][N], Tp = sg_wino_plane_rows(B, H, W) = B H/2 W/2 rounded up to 128.
+ *        workspace: sg_wino_workspace_bytes(B, H, W, Cin, Cout, tile) bytes of device memory, caller-provided, contents scratch:
+ *            V [P][Tp][K] followed by Mt [P][Tp][N], P = (tile+2)^2, Tp = sg_wino_plane_rows(B, H, W, tile) = B H/tile W/tile
+ *            rounded up to 128.
  *      The three steps are also exported one by one (the host side times the HBM-bound transforms apart from the
  *      matrix-bound product): sg_wino_input (x [B,H,W,C] -> V, relu != 0 applies max(.,0) to x), sg_wino_gemm
- *      (Mt[f] = V[f] U[f]^T for the 16 frequencies in one grouped launch), sg_wino_output (Mt -> y with bias + bias2, ReLU
+ *      (Mt[f] = V[f] U[f]^T for all planes in one grouped launch), sg_wino_output (Mt -> y with bias + bias2, ReLU
  *      mask, SG_ACCUM, SG_RELU_OUT). */
-long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-long sg_wino_plane_rows(int B, int H, int W);
-int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, void* stream);
-int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream);
+long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
+long sg_wino_plane_rows(int B, int H, int W, int tile);
+int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, int tile, void* stream);
+int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, void* stream);
+int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, int tile, void* stream);
 int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask,
-                   int B, int H, int W, int N, int flags, void* stream);
-int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, void* stream);
+                   int B, int H, int W, int N, int flags, int tile, void* stream);
 int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, const float* bias2, float* y,
-                       int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+                       int B, int H, int W, int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream);
 int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx,
-                            int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+                            int B, int H, int W, int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream);
 /*      Weight gradient in the same domain (contract of sg_conv2d_bwd_weight, resnet_ops.py:65,98,103 under the tape: dw += ,
  *      db += when non-null, sample_scale [B] nullable, SG_RELU_IN on x): dU[f] = V[f]^T Qt[f] over the tiles with
  *      Qt = A dy A^T (sg_wino_grad_input: rows scaled by sample_scale[b], db += their column sums), then dw += G^T dU G
- *      (sg_wino_filter_grad).  sg_wino_wgrad_gemm overwrites dU [16][Cin][Cout]; partial sums of the tile chunks meet through
+ *      (sg_wino_filter_grad).  sg_wino_wgrad_gemm overwrites dU [P][Cin][Cout]; partial sums of the tile chunks meet through
  *      float atomics (one chunk in deterministic mode).  Workspace: sg_wino_wgrad_workspace_bytes = V | Qt | dU. */
-long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, void* stream);
-int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, void* stream);
-int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, void* stream);
+long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
+int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, int tile, void* stream);
+int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, void* stream);
+int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, int tile, void* stream);
 int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale,
-                              int B, int H, int W, int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream);
+                              int B, int H, int W, int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- second-generation bf16 path: bf16 ACTIVATIONS in HBM, operand tiles moved global -> LDS by DMA (round 2).
  *      sg_cvt_bf16: fp32 [n] -> bf16 [n] (round to nearest even), n % 8 == 0; relu != 0 applies max(.,0) first; rowscale

@@ -20,15 +20,12 @@
 // the grouped product: a tile never straddles two frequencies; 128 rather than 256 rows because the 8-way shard batch has
 // T = 320 on the 4x20 layers); the pad rows are never written nor read back.
 #include "sg_conv2.h"
+#include "wino_f43.h"
 
 #define WINO_F 16
 
 static inline long wino_tp(long T) { return (T + 127) / 128 * 128; }      // (the grouped product runs on 128-row tiles)
 
-extern "C" long sg_wino_plane_rows(int B, int H, int W) {
-  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
-  return wino_tp((long)B * (H / 2) * (W / 2));
-}
 
 // ---- filter transform: in [3][3][N][K] (fp32) -> U [16][N][K];  flip != 0 reads tap (2 - a, 2 - b) for (a, b)
 __global__ __launch_bounds__(256) void k_wino_filter(const float* __restrict__ in, float* __restrict__ U, long NK, int flip) {
@@ -248,47 +245,254 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ dU, f
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// C-ABI (include/scrabble_hip.h)
-// ------------------------------------------------------------------------------------------
-static bool wino_shape_ok(int B, int H, int W, int K, int N) {
-  return B > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && K > 0 && N > 0 && !(K % 32) && !(N % 64);
+// ==========================================================================================================
+// F(4x4, 3x3): 36 products per 4x4 output tile (2.25 per output against F(2x2)'s 4 and the direct form's 9), 6x6 input patches,
+// V / Mt are 2.25x the activation (F(2x2): 4x).  1-D transforms from wino_f43.h (generated: Cook-Toom over {0, +-1/2, +-3/2, inf},
+// the point set with the smallest fp32 error in an emulation of this pipeline -- tools/gen_winograd_f43.py), applied along the
+// columns, then along the rows.  Same kernels-and-planes structure as above with 36 planes; tiles t = (b * H/4 + ty) * W/4 + tx.
+// ==========================================================================================================
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+__device__ __forceinline__ void st4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+__device__ __forceinline__ v4f relu4v(v4f v) { return __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f}); }
+
+__global__ __launch_bounds__(256) void k_w43_filter(const float* __restrict__ in, float* __restrict__ U, long NK, int flip) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < NK; e += (long)gridDim.x * 256) {
+    float g[3][3], h[6][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g[a][b] = in[(size_t)((flip ? 2 - a : a) * 3 + (flip ? 2 - b : b)) * NK + e];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) w43_g(g[0][b], g[1][b], g[2][b], h[0][b], h[1][b], h[2][b], h[3][b], h[4][b], h[5][b]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float u0, u1, u2, u3, u4, u5;
+      w43_g(h[i][0], h[i][1], h[i][2], u0, u1, u2, u3, u4, u5);
+      float* o = U + (size_t)(i * 6) * NK + e;
+      o[0] = u0; o[(size_t)NK] = u1; o[(size_t)2 * NK] = u2; o[(size_t)3 * NK] = u3; o[(size_t)4 * NK] = u4; o[(size_t)5 * NK] = u5;
+    }
+  }
 }
 
-extern "C" long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0) return 0;
-  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
-  return (long)sizeof(float) * WINO_F * Tp * ((long)Cin + Cout);
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_w43_in(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, long T, long Tp) {
+  const int C4 = C >> 2, H4 = H >> 2, W4 = W >> 2;
+  const long items = T * C4;
+  const size_t plane = (size_t)Tp * C;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / C4;
+    const int c = (int)(it - t * C4) * 4;
+    const int tx = (int)(t % W4);
+    const long r = t / W4;
+    const int ty = (int)(r % H4);
+    const long b = r / H4;
+    v4f u[6][6];                                   // columns transformed: u[i][j] = sum_a BT[i][a] d[a][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = 4 * tx - 1 + j;
+      v4f d[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int iy = 4 * ty - 1 + a;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        d[a] = RELU ? relu4v(v) : v;
+      }
+      w43_bt(d[0], d[1], d[2], d[3], d[4], d[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+    }
+    float* out = V + (size_t)t * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      v4f o0, o1, o2, o3, o4, o5;
+      w43_bt(u[i][0], u[i][1], u[i][2], u[i][3], u[i][4], u[i][5], o0, o1, o2, o3, o4, o5);
+      float* q = out + (size_t)(i * 6) * plane;
+      st4(q, o0); st4(q + plane, o1); st4(q + 2 * plane, o2); st4(q + 3 * plane, o3); st4(q + 4 * plane, o4); st4(q + 5 * plane, o5);
+    }
+  }
 }
 
-extern "C" int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, void* stream) {
-  if (!w_nk || !u || N <= 0 || K <= 0) return SG_ERR_ARG;
+__global__ __launch_bounds__(256) void k_w43_out(const float* __restrict__ Mt, float* __restrict__ y, const float* __restrict__ bias,
+                                                 const float* __restrict__ bias2, const float* __restrict__ mask, int H, int W, int N, long T,
+                                                 long Tp, int flags) {
+  const int N4 = N >> 2, H4 = H >> 2, W4 = W >> 2;
+  const long items = T * N4;
+  const size_t plane = (size_t)Tp * N;
+  const bool accum = (flags & SG_ACCUM) != 0, relu_out = (flags & SG_RELU_OUT) != 0;
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / N4;
+    const int n = (int)(it - t * N4) * 4;
+    const int tx = (int)(t % W4);
+    const long r = t / W4;
+    const int ty = (int)(r % H4);
+    const long b = r / H4;
+    const float* src = Mt + (size_t)t * N + n;
+    v4f q[4][6];                                   // columns reduced: q[i][j] = sum_a AT[i][a] m[a][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      v4f m[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m[a] = ld4(src + (size_t)(a * 6 + j) * plane);
+      w43_at(m[0], m[1], m[2], m[3], m[4], m[5], q[0][j], q[1][j], q[2][j], q[3][j]);
+    }
+    v4f bs = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bs += ld4(bias + n);
+    if (bias2) bs += ld4(bias2 + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v4f o[4];
+      w43_at(q[i][0], q[i][1], q[i][2], q[i][3], q[i][4], q[i][5], o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v4f v = o[j] + bs;
+        const size_t idx = ((size_t)(b * H + 4 * ty + i) * W + 4 * tx + j) * N + n;
+        if (mask) {
+          const v4f k = ld4(mask + idx);
+          if (k.x <= 0.f) v.x = 0.f;
+          if (k.y <= 0.f) v.y = 0.f;
+          if (k.z <= 0.f) v.z = 0.f;
+          if (k.w <= 0.f) v.w = 0.f;
+        }
+        if (accum) v += ld4(y + idx);
+        if (relu_out) v = relu4v(v);
+        st4(y + idx, v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_w43_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
+                                                float* __restrict__ db, int H, int W, int N, long T, long Tp) {
+  __shared__ float4 red[256];
+  const int N4 = N >> 2, H4 = H >> 2, W4 = W >> 2;
+  const long items = T * N4;
+  const size_t plane = (size_t)Tp * N;
+  const bool fixed_col = ((long)gridDim.x * 256) % N4 == 0;          // (see k_wino_dy)
+  v4f bsum = {0.f, 0.f, 0.f, 0.f};
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const long t = it / N4;
+    const int n = (int)(it - t * N4) * 4;
+    const int tx = (int)(t % W4);
+    const long r = t / W4;
+    const int ty = (int)(r % H4);
+    const long b = r / H4;
+    const float sc = sample_scale ? sample_scale[b] : 1.f;
+    v4f rr[6][4];                                  // columns expanded: rr[i][j] = sum_a A[i][a] d[a][j]
+    v4f s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v4f d[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        d[a] = ld4(dy + ((size_t)(b * H + 4 * ty + a) * W + 4 * tx + j) * N + n) * sc;
+        s4 += d[a];
+      }
+      w43_a(d[0], d[1], d[2], d[3], rr[0][j], rr[1][j], rr[2][j], rr[3][j], rr[4][j], rr[5][j]);
+    }
+    if (db) {
+      if (fixed_col) bsum += s4;
+      else { atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w); }
+    }
+    float* out = Qt + (size_t)t * N + n;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      v4f o0, o1, o2, o3, o4, o5;
+      w43_a(rr[i][0], rr[i][1], rr[i][2], rr[i][3], o0, o1, o2, o3, o4, o5);
+      float* q = out + (size_t)(i * 6) * plane;
+      st4(q, o0); st4(q + plane, o1); st4(q + 2 * plane, o2); st4(q + 3 * plane, o3); st4(q + 4 * plane, o4); st4(q + 5 * plane, o5);
+    }
+  }
+  if (db && fixed_col) {
+    red[threadIdx.x] = make_float4(bsum.x, bsum.y, bsum.z, bsum.w);
+    __syncthreads();
+    const int per = N4 < 256 ? N4 : 256;
+    if ((int)threadIdx.x < per) {
+      float4 s4 = red[threadIdx.x];
+      for (int k = threadIdx.x + per; k < 256; k += per) s4 = f4_add(s4, red[k]);
+      const int n = (int)((((long)blockIdx.x * 256 + threadIdx.x) % N4) * 4);
+      atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_w43_dw(const float* __restrict__ dU, float* __restrict__ dw, long KN) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < KN; e += (long)gridDim.x * 256) {
+    float h[3][6];                                 // columns reduced: h[a][j] = sum_i GT[a][i] u[i][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float u[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) u[i] = dU[(size_t)(i * 6 + j) * KN + e];
+      w43_gt(u[0], u[1], u[2], u[3], u[4], u[5], h[0][j], h[1][j], h[2][j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float g0, g1, g2;
+      w43_gt(h[a][0], h[a][1], h[a][2], h[a][3], h[a][4], h[a][5], g0, g1, g2);
+      dw[(size_t)(a * 3 + 0) * KN + e] += g0;
+      dw[(size_t)(a * 3 + 1) * KN + e] += g1;
+      dw[(size_t)(a * 3 + 2) * KN + e] += g2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI (include/scrabble_hip.h).  tile = 2: F(2x2, 3x3), 16 planes, H and W even;  tile = 4: F(4x4, 3x3), 36 planes, H % 4 == W % 4 == 0.
+// ------------------------------------------------------------------------------------------
+static inline int wino_planes(int tile) { return (tile + 2) * (tile + 2); }
+static bool wino_geom_ok(int B, int H, int W, int tile) {
+  return (tile == 2 || tile == 4) && B > 0 && H > 0 && W > 0 && !(H % tile) && !(W % tile);
+}
+static inline long wino_tiles(int B, int H, int W, int tile) { return (long)B * (H / tile) * (W / tile); }
+static bool wino_shape_ok(int B, int H, int W, int K, int N, int tile) {
+  return wino_geom_ok(B, H, W, tile) && K > 0 && N > 0 && !(K % 32) && !(N % 64);
+}
+
+extern "C" long sg_wino_plane_rows(int B, int H, int W, int tile) {
+  return wino_geom_ok(B, H, W, tile) ? wino_tp(wino_tiles(B, H, W, tile)) : 0;
+}
+
+extern "C" long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile) {
+  if (!wino_geom_ok(B, H, W, tile) || Cin <= 0 || Cout <= 0) return 0;
+  return (long)sizeof(float) * wino_planes(tile) * wino_tp(wino_tiles(B, H, W, tile)) * ((long)Cin + Cout);
+}
+
+extern "C" int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, int tile, void* stream) {
+  if (!w_nk || !u || N <= 0 || K <= 0 || (tile != 2 && tile != 4)) return SG_ERR_ARG;
   const long NK = (long)N * K;
-  SG_KERNEL(k_wino_filter, dim3(sg_grid_for(NK, 256)), dim3(256), 0, (hipStream_t)stream, w_nk, u, NK, flip);
+  if (tile == 2) SG_KERNEL(k_wino_filter, dim3(sg_grid_for(NK, 256)), dim3(256), 0, (hipStream_t)stream, w_nk, u, NK, flip);
+  else SG_KERNEL(k_w43_filter, dim3(sg_grid_for(NK, 256)), dim3(256), 0, (hipStream_t)stream, w_nk, u, NK, flip);
   return sg_launch_status();
 }
 
 // ---- the three steps as separate entry points (the host times them apart: two HBM-bound sweeps around one matrix-bound launch)
-extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, void* stream) {
+extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, void* stream) {
   if (!x || !V) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, C, 64)) return SG_ERR_UNSUPPORTED;
-  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  if (!wino_shape_ok(B, H, W, C, 64, tile)) return SG_ERR_UNSUPPORTED;
+  const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   hipStream_t s = (hipStream_t)stream;
-  if (relu) SG_KERNEL(k_wino_in<true>, dim3(sg_grid_for(T * (C / 4), 256)), dim3(256), 0, s, x, V, H, W, C, T, Tp);
-  else SG_KERNEL(k_wino_in<false>, dim3(sg_grid_for(T * (C / 4), 256)), dim3(256), 0, s, x, V, H, W, C, T, Tp);
+  const dim3 grid(sg_grid_for(T * (C / 4), 256)), block(256);
+  if (tile == 2) {
+    if (relu) SG_KERNEL(k_wino_in<true>, grid, block, 0, s, x, V, H, W, C, T, Tp);
+    else SG_KERNEL(k_wino_in<false>, grid, block, 0, s, x, V, H, W, C, T, Tp);
+  } else {
+    if (relu) SG_KERNEL(k_w43_in<true>, grid, block, 0, s, x, V, H, W, C, T, Tp);
+    else SG_KERNEL(k_w43_in<false>, grid, block, 0, s, x, V, H, W, C, T, Tp);
+  }
   return sg_launch_status();
 }
 
-extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, void* stream) {
+extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, int tile, void* stream) {
   if (!V || !u || !Mt) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N) || (N % 128)) return SG_ERR_UNSUPPORTED;
-  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
-  if (WINO_F * Tp >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
+  if (!wino_shape_ok(B, H, W, K, N, tile) || (N % 128)) return SG_ERR_UNSUPPORTED;
+  const long Tp = wino_tp(wino_tiles(B, H, W, tile));
+  const int F = wino_planes(tile);
+  if (F * Tp >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
   SgIgemm2Args g{};
   g.a = reinterpret_cast<const u16*>(V);
   g.w = reinterpret_cast<const u16*>(u);
   g.out = Mt;
-  g.Bn = (int)(WINO_F * Tp); g.Ha = 1; g.Wa = 1; g.Ca = K; g.Hg = 1; g.Wg = 1; g.a_sy = 1; g.a_sx = 1;
+  g.Bn = (int)(F * Tp); g.Ha = 1; g.Wa = 1; g.Ca = K; g.Hg = 1; g.Wg = 1; g.a_sy = 1; g.a_sx = 1;
   g.Ho = 1; g.Wo = 1; g.N = N; g.o_sy = 1; g.o_sx = 1; g.o_oy = 0; g.o_ox = 0;
   g.ntaps = 1; g.flags = 0;
   g.taps[0] = SgTap{0, 0, 0};
@@ -299,95 +503,103 @@ extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, in
 }
 
 extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask, int B, int H, int W, int N,
-                              int flags, void* stream) {
+                              int flags, int tile, void* stream) {
   if (!Mt || !y) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, 32, N) || (flags & (SG_TANH_OUT | SG_RELU_IN))) return SG_ERR_UNSUPPORTED;
-  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
-  SG_KERNEL(k_wino_out, dim3(sg_grid_for(T * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+  if (!wino_shape_ok(B, H, W, 32, N, tile) || (flags & (SG_TANH_OUT | SG_RELU_IN))) return SG_ERR_UNSUPPORTED;
+  const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
+  const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
+  if (tile == 2) SG_KERNEL(k_wino_out, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+  else SG_KERNEL(k_w43_out, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
   return sg_launch_status();
 }
 
-// a [B,H,W,K] -> out [B,H,W,N] through the three steps; u [16][N][K]
+// a [B,H,W,K] -> out [B,H,W,N] through the three steps; u [planes][N][K]
 static int wino_conv(const float* a, const float* u, const float* bias, const float* bias2, const float* mask, float* out, int B, int H, int W,
-                     int K, int N, int flags, void* workspace, long workspace_bytes, hipStream_t s) {
+                     int K, int N, int flags, int tile, void* workspace, long workspace_bytes, hipStream_t s) {
   if (!a || !u || !out || !workspace) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N) || (N % 128) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
-  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
-  if (workspace_bytes < (long)sizeof(float) * WINO_F * Tp * ((long)K + N)) return SG_ERR_ARG;
+  if (!wino_shape_ok(B, H, W, K, N, tile) || (N % 128) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
+  if (workspace_bytes < sg_wino_workspace_bytes(B, H, W, K, N, tile)) return SG_ERR_ARG;
+  const long Tp = wino_tp(wino_tiles(B, H, W, tile));
   float* V = reinterpret_cast<float*>(workspace);
-  float* Mt = V + (size_t)WINO_F * Tp * K;
-  int rc = sg_wino_input(a, V, B, H, W, K, (flags & SG_RELU_IN) != 0, s);
+  float* Mt = V + (size_t)wino_planes(tile) * Tp * K;
+  int rc = sg_wino_input(a, V, B, H, W, K, (flags & SG_RELU_IN) != 0, tile, s);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_gemm(V, u, Mt, B, H, W, K, N, s);
+  rc = sg_wino_gemm(V, u, Mt, B, H, W, K, N, tile, s);
   if (rc != SG_OK) return rc;
-  return sg_wino_output(Mt, out, bias, bias2, mask, B, H, W, N, flags & ~SG_RELU_IN, s);
+  return sg_wino_output(Mt, out, bias, bias2, mask, B, H, W, N, flags & ~SG_RELU_IN, tile, s);
 }
 
 extern "C" int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, const float* bias2, float* y, int B, int H, int W,
-                                  int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
-  return wino_conv(x, u_fwd, bias, bias2, nullptr, y, B, H, W, Cin, Cout, flags, workspace, workspace_bytes, (hipStream_t)stream);
+                                  int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream) {
+  return wino_conv(x, u_fwd, bias, bias2, nullptr, y, B, H, W, Cin, Cout, flags, tile, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx, int B, int H, int W, int Cin,
-                                       int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
+                                       int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream) {
   if (flags & (SG_RELU_IN | SG_RELU_OUT)) return SG_ERR_ARG;
-  return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, workspace, workspace_bytes, (hipStream_t)stream);
+  return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, tile, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// ---- weight gradient: workspace = V [16][Tp][Cin] | Qt [16][Tp][Cout] | dU [16][Cin][Cout]
-extern "C" long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-  if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cin <= 0 || Cout <= 0) return 0;
-  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
-  return (long)sizeof(float) * WINO_F * (Tp * ((long)Cin + Cout) + (long)Cin * Cout);
+// ---- weight gradient: workspace = V [planes][Tp][Cin] | Qt [planes][Tp][Cout] | dU [planes][Cin][Cout]
+extern "C" long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile) {
+  if (!wino_geom_ok(B, H, W, tile) || Cin <= 0 || Cout <= 0) return 0;
+  const long Tp = wino_tp(wino_tiles(B, H, W, tile));
+  return (long)sizeof(float) * wino_planes(tile) * (Tp * ((long)Cin + Cout) + (long)Cin * Cout);
 }
 
-extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, void* stream) {
+extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, int tile,
+                                  void* stream) {
   if (!dy || !Qt) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, 32, 64) || (N & 3) || N <= 0) return SG_ERR_UNSUPPORTED;
-  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
-  SG_KERNEL(k_wino_dy, dim3(sg_grid_for(T * (N / 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  if (!wino_geom_ok(B, H, W, tile) || (N & 3) || N <= 0) return SG_ERR_UNSUPPORTED;
+  const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
+  const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
+  if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  else SG_KERNEL(k_w43_dy, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
   return sg_launch_status();
 }
 
-// dU [16][K][N] = sum over the T tiles of V[f]^T Qt[f] (dU is overwritten)
-extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, void* stream) {
+// dU [planes][K][N] = sum over the T tiles of V[f]^T Qt[f] (dU is overwritten)
+extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, void* stream) {
   if (!V || !Qt || !dU) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, 32, 64) || (K & 3) || (N & 3) || K <= 0 || N <= 0) return SG_ERR_UNSUPPORTED;
-  const long T = (long)B * (H / 2) * (W / 2), Tp = wino_tp(T);
+  if (!wino_geom_ok(B, H, W, tile) || (K & 3) || (N & 3) || K <= 0 || N <= 0) return SG_ERR_UNSUPPORTED;
+  const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   if (T >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
+  const int F = wino_planes(tile);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dU, 0, sizeof(float) * (size_t)WINO_F * K * N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  if (hipMemsetAsync(dU, 0, sizeof(float) * (size_t)F * K * N, s) != hipSuccess) return SG_ERR_LAUNCH;
   SgWgradArgs a{};
   a.p = V; a.q = Qt; a.dw = dU;
   a.Bn = (int)T; a.Hp = 1; a.Wp = 1; a.Cp = K; a.p_sy = 1; a.p_sx = 1;
   a.Hq = 1; a.Wq = 1; a.Cq = N; a.q_sy = 1; a.q_sx = 1; a.Hg = 1; a.Wg = 1;
-  a.ntaps = WINO_F; a.flags = 0;
+  a.ntaps = F; a.flags = 0;
   a.p_plane = Tp * K;
   a.q_plane = Tp * N;
   return sg_launch_wgrad(a, s);
 }
 
-extern "C" int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, void* stream) {
-  if (!dU || !dw || K <= 0 || N <= 0) return SG_ERR_ARG;
+extern "C" int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, int tile, void* stream) {
+  if (!dU || !dw || K <= 0 || N <= 0 || (tile != 2 && tile != 4)) return SG_ERR_ARG;
   const long KN = (long)K * N;
-  SG_KERNEL(k_wino_dw, dim3(sg_grid_for(KN, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, KN);
+  if (tile == 2) SG_KERNEL(k_wino_dw, dim3(sg_grid_for(KN, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, KN);
+  else SG_KERNEL(k_w43_dw, dim3(sg_grid_for(KN, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, KN);
   return sg_launch_status();
 }
 
 extern "C" int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale, int B, int H, int W,
-                                         int Cin, int Cout, int flags, void* workspace, long workspace_bytes, void* stream) {
+                                         int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream) {
   if (!x || !dy || !dw || !workspace) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, Cin, 64) || (Cout & 3)) return SG_ERR_UNSUPPORTED;
-  if (workspace_bytes < sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return SG_ERR_ARG;
-  const long Tp = wino_tp((long)B * (H / 2) * (W / 2));
+  if (!wino_shape_ok(B, H, W, Cin, 64, tile) || (Cout & 3)) return SG_ERR_UNSUPPORTED;
+  if (workspace_bytes < sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)) return SG_ERR_ARG;
+  const long Tp = wino_tp(wino_tiles(B, H, W, tile));
+  const int F = wino_planes(tile);
   float* V = reinterpret_cast<float*>(workspace);
-  float* Qt = V + (size_t)WINO_F * Tp * Cin;
-  float* dU = Qt + (size_t)WINO_F * Tp * Cout;
-  int rc = sg_wino_input(x, V, B, H, W, Cin, (flags & SG_RELU_IN) != 0, stream);
+  float* Qt = V + (size_t)F * Tp * Cin;
+  float* dU = Qt + (size_t)F * Tp * Cout;
+  int rc = sg_wino_input(x, V, B, H, W, Cin, (flags & SG_RELU_IN) != 0, tile, stream);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, B, H, W, Cout, stream);
+  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, B, H, W, Cout, tile, stream);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, stream);
+  rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, tile, stream);
   if (rc != SG_OK) return rc;
-  return sg_wino_filter_grad(dU, dw, Cin, Cout, stream);
+  return sg_wino_filter_grad(dU, dw, Cin, Cout, tile, stream);
 }

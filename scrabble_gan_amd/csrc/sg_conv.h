@@ -46,10 +46,10 @@ struct SgWgradArgs {
   unsigned p_bytes, q_bytes;   // extents of p and q for the buffer-load range check (filled in by sg_launch_wgrad)
   SgTap taps[SG_MAX_TAPS];
   // grouped form (conv_winograd.hip; fp32 kernel only): p_plane > 0 makes "tap" t an independent product -- P = p + t * p_plane,
-  // Q = q + t * q_plane (elements), no pixel shift, dW_t at dw + t * Cp * Cq; the tap table is not read and ntaps may reach 16
+  // Q = q + t * q_plane (elements), no pixel shift, dW_t at dw + t * Cp * Cq; the tap table is not read and ntaps may reach SG_MAX_GROUPS
   long p_plane, q_plane;
 };
-#define SG_MAX_GROUPS 16
+#define SG_MAX_GROUPS 36
 
 struct SgThinArgs {
   const float* a;

@@ -508,12 +508,13 @@ def packed_filter(w: torch.Tensor, kind: str) -> torch.Tensor:
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
     kh, kw, Cin, Cout = w.shape
-    if kind in ("wino_fwd", "wino_bwd"):   # Winograd-domain filters U [16][N][K] (conv_winograd.hip)
-        out = torch.empty(16, Cout * Cin, device=w.device, dtype=torch.float32)
-        if kind == "wino_fwd":
-            call("sg_wino_filter", _p(packed_filter(w, "fwd_f32t")), _p(out), Cout, Cin, 0, _stream())
+    if kind in ("wino_fwd2", "wino_bwd2", "wino_fwd4", "wino_bwd4"):   # Winograd-domain filters U [(tile+2)^2][N][K] (conv_winograd.hip)
+        tile = int(kind[-1])
+        out = torch.empty((tile + 2) ** 2, Cout * Cin, device=w.device, dtype=torch.float32)
+        if kind.startswith("wino_fwd"):
+            call("sg_wino_filter", _p(packed_filter(w, "fwd_f32t")), _p(out), Cout, Cin, 0, tile, _stream())
         else:
-            call("sg_wino_filter", _p(w), _p(out), Cin, Cout, 1, _stream())
+            call("sg_wino_filter", _p(w), _p(out), Cin, Cout, 1, tile, _stream())
         _PACK_CACHE[key] = (w, out)
         return out
     out = None if kind in ("bwd_f32", "fwd_f32t") else torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
@@ -701,7 +702,12 @@ USE_WINOGRAD = _os.environ.get("SG_WINOGRAD", "1") == "1"
 # 1.6-2.0x over >= 512 channels, 1.3-1.5x at 256, 1.1-1.3x at 128 -> 256 (R.conv3), 0.9x at 128 -> 128 and below.
 WINO_MIN_C = int(_os.environ.get("SG_WINO_MIN_C", "128"))        # both channel counts at least this ...
 WINO_MIN_KN = int(_os.environ.get("SG_WINO_MIN_KN", "32768"))    # ... and their product at least this (tests: 32 / 0)
+WINO_TILE = int(_os.environ.get("SG_WINO_TILE", "2"))           # 4: F(4x4, 3x3) where H % 4 == W % 4 == 0 (else F(2x2, 3x3))
 _WINO_WS = {}              # raw stream handle -> scratch buffer (V and Mt of the launch in flight on that stream)
+
+
+def _wino_tile(H: int, W: int) -> int:
+    return 4 if (WINO_TILE == 4 and H % 4 == 0 and W % 4 == 0) else 2
 
 
 def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
@@ -722,27 +728,39 @@ def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
     return buf
 
 
-def _wino_conv(a, u, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flags: int, tag) -> None:
-    """out [B,H,W,N] = conv3x3_same(a [B,H,W,K]) through input transform -> 16 grouped products -> output transform."""
+def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flags: int, tag) -> None:
+    """out [B,H,W,N] = conv3x3_same(a [B,H,W,K]) through input transform -> grouped products -> output transform (tag[0] = "wino_fwd":
+    forward of the filter w; "wino_dgrad": its data-grad)."""
     B, H, W, _ = a.shape
-    T = B * (H // 2) * (W // 2)
-    Tp = lib().sg_wino_plane_rows(B, H, W)
-    ws = _wino_workspace(lib().sg_wino_workspace_bytes(B, H, W, K, N), a)
+    tile = _wino_tile(H, W)
+    P = (tile + 2) ** 2
+    fwd = tag[0] == "wino_fwd"
+    u = packed_filter(w, ("wino_fwd%d" if fwd else "wino_bwd%d") % tile)
+    T = B * (H // tile) * (W // tile)
+    Tp = -(-T // 128) * 128                 # = sg_wino_plane_rows(B, H, W, tile)
+    nbytes = 4 * P * Tp * (K + N)           # = sg_wino_workspace_bytes(B, H, W, K, N, tile)
+    ws = _wino_workspace(nbytes, a)
     V = ws.data_ptr()
-    Mt = V + 4 * 16 * Tp * K
+    Mt = V + 4 * P * Tp * K
     s = _stream()
+    if PROFILER is None:                    # one call for the three launches (the host queues a shard-size step in half its GPU time)
+        if fwd:
+            call("sg_conv2d_fwd_wino", _p(a), _p(u), _p(bias), _p(bias2), _p(out), B, H, W, K, N, flags | (1 if relu_in else 0), tile, V, nbytes, s)
+        else:
+            call("sg_conv2d_bwd_data_wino", _p(a), _p(u), _p(mask), _p(out), B, H, W, N, K, flags, tile, V, nbytes, s)
+        return
     with _hbm("wino_transform", a, flops=0.0) as _:
         if PROFILER is not None and PROFILER.wants("wino_transform"):
-            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * K
-        call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), s)
-    with _timed("igemm_wino", 2.0 * 16 * Tp * K * N, False, tag):        # (executed FLOPs: the sixteen products, pad rows included)
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * K
+        call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), tile, s)
+    with _timed("igemm_wino", 2.0 * P * Tp * K * N, False, tag):        # (executed FLOPs: the grouped products, pad rows included)
         if PROFILER is not None and PROFILER.wants("igemm_wino"):
-            PROFILER.nbytes["igemm_wino"] = PROFILER.nbytes.get("igemm_wino", 0.0) + 4.0 * 16 * (Tp * K + N * K + Tp * N)
-        call("sg_wino_gemm", V, _p(u), Mt, B, H, W, K, N, s)
+            PROFILER.nbytes["igemm_wino"] = PROFILER.nbytes.get("igemm_wino", 0.0) + 4.0 * P * (Tp * K + N * K + Tp * N)
+        call("sg_wino_gemm", V, _p(u), Mt, B, H, W, K, N, tile, s)
     with _hbm("wino_transform", out, mask, flops=0.0):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
-            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * N
-        call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags, s)
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * N
+        call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags, tile, s)
 
 
 def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
@@ -755,26 +773,32 @@ def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W:
 def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
-    T = B * (H // 2) * (W // 2)
-    Tp = lib().sg_wino_plane_rows(B, H, W)
-    ws = _wino_workspace(lib().sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout), x)
+    tile = _wino_tile(H, W)
+    P = (tile + 2) ** 2
+    T = B * (H // tile) * (W // tile)
+    Tp = -(-T // 128) * 128
+    nbytes = 4 * P * (Tp * (Cin + Cout) + Cin * Cout)          # = sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)
+    ws = _wino_workspace(nbytes, x)
     V = ws.data_ptr()
-    Qt = V + 4 * 16 * Tp * Cin
-    dU = Qt + 4 * 16 * Tp * Cout
+    Qt = V + 4 * P * Tp * Cin
+    dU = Qt + 4 * P * Tp * Cout
     s = _stream()
+    if PROFILER is None:
+        call("sg_conv2d_bwd_weight_wino", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, 1 if relu_in else 0, tile, V, nbytes, s)
+        return
     with _hbm("wino_transform", x, dy):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
-            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * T * (Cin + Cout)
-        call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), s)
-        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), B, H, W, Cout, s)
-    with _timed("wgrad_wino", 2.0 * 16 * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * (Cin + Cout)
+        call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), tile, s)
+        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), B, H, W, Cout, tile, s)
+    with _timed("wgrad_wino", 2.0 * P * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
         if PROFILER is not None and PROFILER.wants("wgrad_wino"):
-            PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * 16 * (T * (Cin + Cout) + Cin * Cout)
-        call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, s)
+            PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * P * (T * (Cin + Cout) + Cin * Cout)
+        call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, tile, s)
     with _hbm("wino_transform", dw, dw):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
-            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * 16 * Cin * Cout
-        call("sg_wino_filter_grad", dU, _p(dw), Cin, Cout, s)
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * Cin * Cout
+        call("sg_wino_filter_grad", dU, _p(dw), Cin, Cout, tile, s)
 
 
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
@@ -802,7 +826,7 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
             out.fill_(float("nan"))
         _TWINS[(out.untyped_storage().data_ptr(), "ghost")] = (out,)
     if _wino_ok(Cin, Cout, kh, kw, same, H, W) and not tanh_out:
-        _wino_conv(x, packed_filter(w, "wino_fwd"), out, bias, bias2, None, Cin, Cout, relu_in, _flags(False, accum, relu_out),
+        _wino_conv(x, w, out, bias, bias2, None, Cin, Cout, relu_in, _flags(False, accum, relu_out),
                    ("wino_fwd", B, Ho, Wo, Cin, Cout, kh))
         return out
     with _timed("igemm_fp8" if use8 else "igemm", 2.0 * B * Ho * Wo * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,
@@ -852,7 +876,7 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
         out = empty(B, H, W, Cin, like=dy)
     use8 = _fp8_ok(Cout, Cin, kh, kw, same)
     if _wino_ok(Cout, Cin, kh, kw, same, H, W) and tuple(dy.shape[1:3]) == (H, W):
-        _wino_conv(dy, packed_filter(w, "wino_bwd"), out, None, None, mask, Cout, Cin, False, _flags(accum=accum),
+        _wino_conv(dy, w, out, None, None, mask, Cout, Cin, False, _flags(accum=accum),
                    ("wino_dgrad", B, H, W, Cin, Cout, kh))
         return out
     with _timed("igemm_fp8" if use8 else "igemm", 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * kh * kw * Cin * Cout, Cin == 1 or Cout == 1,

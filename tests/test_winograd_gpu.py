@@ -17,14 +17,24 @@ from oracle import scrabble_oracle as O  # checker only
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def wino_everywhere():
-    """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path."""
+@pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
+def wino_everywhere(request):
+    """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path; F4x4: F(4x4, 3x3) wherever H and W
+    are multiples of 4 (the other shapes of the lists then run F(2x2, 3x3) again)."""
     from scrabble_gan_amd import ops
-    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD)
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD = 32, 0, True
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE = 32, 0, True, request.param
     yield ops
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD = old
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE = old
+
+
+@pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
+def wino_tile(request):
+    from scrabble_gan_amd import ops
+    old = ops.WINO_TILE
+    ops.WINO_TILE = request.param
+    yield request.param
+    ops.WINO_TILE = old
 
 
 def _close(got, ref, tol, name):
@@ -37,7 +47,7 @@ def _close(got, ref, tol, name):
 
 # B, H, W, Cin, Cout: one tile per sample; tile counts below / not a multiple of the 128-row plane padding; odd batches; the
 # recognizer-like wide rows; Cin != Cout both ways (the data-grad runs when Cin % 128 == 0 too)
-SMALL = [(1, 2, 2, 32, 128), (3, 2, 4, 128, 128), (5, 4, 10, 96, 128), (2, 8, 40, 256, 128), (7, 6, 6, 32, 384), (2, 16, 80, 64, 128),
+SMALL = [(1, 2, 2, 32, 128), (1, 4, 4, 32, 128), (3, 4, 8, 128, 128), (3, 2, 4, 128, 128), (5, 4, 10, 96, 128), (2, 8, 40, 256, 128), (7, 6, 6, 32, 384), (2, 16, 80, 64, 128),
          (33, 4, 20, 256, 256), (16, 4, 20, 128, 256)]
 
 
@@ -75,7 +85,7 @@ def test_forward_and_data_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cou
     _close(acc, ref, 2e-5, "dx (mask, accumulate)")
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,scaled", [(3, 2, 4, 64, 64, False), (5, 4, 10, 96, 128, True), (2, 8, 40, 128, 64, True),
+@pytest.mark.parametrize("B,H,W,Cin,Cout,scaled", [(3, 2, 4, 64, 64, False), (3, 4, 8, 64, 64, True), (5, 4, 10, 96, 128, True), (2, 8, 40, 128, 64, True),
                                                    (7, 6, 6, 64, 192, False), (33, 4, 20, 256, 256, True), (16, 8, 40, 512, 1024, True)])
 def test_weight_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cout, scaled):
     """dW += and the bias gradient of the same sweep, with the per-sample factors of the shared backward sweep (`scaled`) and the
@@ -98,7 +108,7 @@ def test_weight_grad_vs_oracle(dev, wino_everywhere, B, H, W, Cin, Cout, scaled)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(128, 16, 80, 512, 512), (48, 8, 40, 1024, 1024), (16, 4, 20, 1024, 1024), (24, 8, 40, 512, 1024)])
-def test_agrees_with_the_direct_kernels_at_launch_geometry(dev, B, H, W, Cin, Cout):
+def test_agrees_with_the_direct_kernels_at_launch_geometry(dev, wino_tile, B, H, W, Cin, Cout):
     """The same launch through both forms (SG_WINOGRAD on / off) at the headline batch and the 8-way shard batch: both are held to
     2e-5 (dW, db: 1e-4) of the fp64 oracle elsewhere, so they may differ by twice that."""
     from scrabble_gan_amd import ops
@@ -140,36 +150,39 @@ def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
     w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
     b = torch.randn(Cout, device=dev, generator=g)
     dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
-    nbytes = L.sg_wino_workspace_bytes(B, H, W, Cin, Cout)
-    T = B * (H // 2) * (W // 2)
-    assert L.sg_wino_plane_rows(B, H, W) == -(-T // 128) * 128 and nbytes == 4 * 16 * (-(-T // 128) * 128) * (Cin + Cout)
+    tile = ops._wino_tile(H, W)
+    P = (tile + 2) ** 2
+    nbytes = L.sg_wino_workspace_bytes(B, H, W, Cin, Cout, tile)
+    T = B * (H // tile) * (W // tile)
+    assert L.sg_wino_plane_rows(B, H, W, tile) == -(-T // 128) * 128 and nbytes == 4 * P * (-(-T // 128) * 128) * (Cin + Cout)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     s = ops._stream()
     y = torch.empty(B, H, W, Cout, device=dev)
-    u = ops.packed_filter(w, "wino_fwd")
-    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, 1, ws.data_ptr(), nbytes, s) == 0
+    u = ops.packed_filter(w, "wino_fwd%d" % tile)
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, H, W, Cin, Cout, 1, tile, ws.data_ptr(), nbytes, s) == 0
     assert torch.equal(y, ops.conv2d_fwd(x, w, b, relu_in=True))
     dx = torch.empty(B, H, W, Cin, device=dev)
-    ub = ops.packed_filter(w, "wino_bwd")
-    assert L.sg_conv2d_bwd_data_wino(dy.data_ptr(), ub.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == 0
+    ub = ops.packed_filter(w, "wino_bwd%d" % tile)
+    assert L.sg_conv2d_bwd_data_wino(dy.data_ptr(), ub.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, 0, tile, ws.data_ptr(), nbytes, s) == 0
     assert torch.equal(dx, ops.conv2d_bwd_data(dy, w, (H, W), mask=x))
-    nb2 = L.sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)
-    assert nb2 == nbytes + 4 * 16 * Cin * Cout
+    nb2 = L.sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)
+    assert nb2 == nbytes + 4 * P * Cin * Cout
     ws2 = torch.empty(nb2, device=dev, dtype=torch.uint8)
     dw, db = torch.zeros_like(w), torch.zeros_like(b)
-    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, H, W, Cin, Cout, 1, ws2.data_ptr(), nb2, s) == 0
+    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, H, W, Cin, Cout, 1, tile, ws2.data_ptr(), nb2, s) == 0
     dw_h, db_h = torch.zeros_like(w), torch.zeros_like(b)
     ops.conv2d_bwd_weight(x, dy, dw_h, relu_in=True, db=db_h)
     _close(dw, dw_h, 1e-5, "dW: C entry vs host path (float-atomic order only)")
     _close(db, db_h, 1e-5, "db: C entry vs host path")
-    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, None, B, H, W, Cin, Cout, 1, ws2.data_ptr(), nb2 - 1, s) == -1
-    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, H, W, Cin, Cout, 0, ws.data_ptr(), nbytes - 1, s) == -1
-    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, 3, W, Cin, Cout, 0, ws.data_ptr(), nbytes, s) == -3
-    assert L.sg_wino_workspace_bytes(B, 3, W, Cin, Cout) == 0
+    assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, None, B, H, W, Cin, Cout, 1, tile, ws2.data_ptr(), nb2 - 1, s) == -1
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, H, W, Cin, Cout, 0, tile, ws.data_ptr(), nbytes - 1, s) == -1
+    assert L.sg_conv2d_fwd_wino(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), B, 3, W, Cin, Cout, 0, tile, ws.data_ptr(), nbytes, s) == -3
+    assert L.sg_wino_workspace_bytes(B, 3, W, Cin, Cout, tile) == 0 and L.sg_wino_workspace_bytes(B, H, W, Cin, Cout, 3) == 0
 
 
 def test_filter_transform_vs_definition(dev):
-    """U = G g G^T per channel pair, forward layout [16][Cout][Cin] and mirrored-tap data-grad layout [16][Cin][Cout]."""
+    """U = G g G^T per channel pair, forward layout [16][Cout][Cin] and mirrored-tap data-grad layout [16][Cin][Cout] (F(2x2, 3x3);
+    the F(4x4, 3x3) matrices are generated and checked in fp64 by tools/gen_winograd_f43.py and exercised by the oracle tests above)."""
     from scrabble_gan_amd import ops
     Cin, Cout = 32, 64
     g = torch.Generator(device=dev).manual_seed(3)
@@ -178,11 +191,11 @@ def test_filter_transform_vs_definition(dev):
     wd = w.double().cpu()
     uf = torch.einsum("ia,abck,jb->ijkc", G, wd, G).reshape(16, Cout * Cin)
     ub = torch.einsum("ia,abck,jb->ijck", G, wd.flip(0, 1), G).reshape(16, Cin * Cout)
-    assert (ops.packed_filter(w, "wino_fwd").double().cpu() - uf).abs().max().item() < 1e-6
-    assert (ops.packed_filter(w, "wino_bwd").double().cpu() - ub).abs().max().item() < 1e-6
+    assert (ops.packed_filter(w, "wino_fwd2").double().cpu() - uf).abs().max().item() < 1e-6
+    assert (ops.packed_filter(w, "wino_bwd2").double().cpu() - ub).abs().max().item() < 1e-6
 
 
-def test_sample_results_do_not_depend_on_the_batch_in_deterministic_mode(dev):
+def test_sample_results_do_not_depend_on_the_batch_in_deterministic_mode(dev, wino_tile):
     """Deterministic mode (no reduction split): a sample's result is bitwise the same alone and inside a batch, run to run."""
     from scrabble_gan_amd import ops
     H, W, C = 4, 20, 1024

@@ -1,6 +1,6 @@
 """Direct vs Winograd-domain launches of the fp32 3x3 convolutions, per layer shape and direction (ms per launch):
 where the 16 / 36 product count pays for the two transform sweeps (-> ops.WINO_MIN_C / WINO_MIN_KN).
-    python tools/probe_winograd.py [--iters 5]"""
+    python tools/probe_winograd.py [--iters 5]            (SG_WINO_TILE=4: F(4x4, 3x3) where H and W allow)"""
 import argparse
 import os
 import sys

@@ -698,11 +698,16 @@ def _f32v2_ok(K: int, N: int, kh: int, kw: int, same: bool, pixels: int) -> bool
 
 # ---- Winograd-domain fp32 3x3 convolutions (conv_winograd.hip) --------------------------------------------------------
 USE_WINOGRAD = _os.environ.get("SG_WINOGRAD", "1") == "1"
-# Where the 16 / 36 product count pays for the transform sweeps (profiles/r03_probe_winograd.txt, direct / Winograd time per launch):
-# 1.6-2.0x over >= 512 channels, 1.3-1.5x at 256, 1.1-1.3x at 128 -> 256 (R.conv3), 0.9x at 128 -> 128 and below.
-WINO_MIN_C = int(_os.environ.get("SG_WINO_MIN_C", "128"))        # both channel counts at least this ...
-WINO_MIN_KN = int(_os.environ.get("SG_WINO_MIN_KN", "32768"))    # ... and their product at least this (tests: 32 / 0)
-WINO_TILE = int(_os.environ.get("SG_WINO_TILE", "2"))           # 4: F(4x4, 3x3) where H % 4 == W % 4 == 0 (else F(2x2, 3x3))
+# F(4x4, 3x3) -- 36 products per 4x4 outputs, 2.25 per output against 4 for F(2x2, 3x3) and 9 for the direct form -- wherever H and W
+# are multiples of 4 (every layer of the fixed-width step); F(2x2, 3x3) on the remaining even shapes (odd word lengths of the
+# bucketed widths: W = 2 L on the 4-row layers).  SG_WINO_TILE=2 keeps F(2x2) everywhere.
+WINO_TILE = int(_os.environ.get("SG_WINO_TILE", "4"))
+# Where the reduced product count pays for the transform sweeps (profiles/r03_probe_winograd.txt, direct / Winograd time per launch):
+# F(2x2): 1.6-2.0x over >= 512 channels, 1.3-1.5x at 256, 1.1-1.3x at 128 -> 256, 0.9x at 128 -> 128 and below;
+# F(4x4): 2.7-3.3x over >= 512 channels, 2.0-2.5x at 256, 1.4-1.9x at 128, 1.2x (forward) / 1.7x (weight-grad) at 64 -> 512.
+WINO_MIN_C = {2: int(_os.environ.get("SG_WINO_MIN_C", "128")), 4: int(_os.environ.get("SG_WINO4_MIN_C", "64"))}       # both channel counts at least this ...
+WINO_MIN_KN = {2: int(_os.environ.get("SG_WINO_MIN_KN", "32768")), 4: int(_os.environ.get("SG_WINO4_MIN_KN", "16384"))}   # ... and their product at least this
+WINO4_WGRAD_MIN_TILES = 128     # weight-grad: below this many 4x4 tiles the 36 reductions are too short (B = 16 on the 4x20 layers) -> F(2x2)
 _WINO_WS = {}              # raw stream handle -> scratch buffer (V and Mt of the launch in flight on that stream)
 
 
@@ -711,8 +716,10 @@ def _wino_tile(H: int, W: int) -> int:
 
 
 def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
-    return (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
-            and K % 32 == 0 and N % 128 == 0 and min(K, N) >= WINO_MIN_C and K * N >= WINO_MIN_KN)
+    if not (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0 and K % 32 == 0 and N % 128 == 0):
+        return False
+    t = _wino_tile(H, W)
+    return min(K, N) >= WINO_MIN_C[t] and K * N >= WINO_MIN_KN[t]
 
 
 def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -764,16 +771,21 @@ def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
 
 
 def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
-    """Weight gradient in the Winograd domain: sixteen [Cin x tiles] x [tiles x Cout] products.  Not in deterministic mode (one
-    pixel chunk per product would leave 256 workgroups for the whole launch: the direct kernel's single-chunk form is used)."""
-    return (USE_WINOGRAD and CONV_DTYPE == "f32" and not DETERMINISTIC and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
-            and Cin % 32 == 0 and Cout % 64 == 0 and min(Cin, Cout) >= WINO_MIN_C and Cin * Cout >= WINO_MIN_KN)
+    """Weight gradient in the Winograd domain: (tile + 2)^2 [Cin x tiles] x [tiles x Cout] products.  Not in deterministic mode (one
+    pixel chunk per product would leave a few hundred workgroups for the whole launch: the direct kernel's single-chunk form is used)."""
+    if not (USE_WINOGRAD and CONV_DTYPE == "f32" and not DETERMINISTIC and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0
+            and Cin % 32 == 0 and Cout % 64 == 0):
+        return False
+    t = _wino_tile(H, W)
+    return min(Cin, Cout) >= WINO_MIN_C[t] and Cin * Cout >= (min(WINO_MIN_KN[4], 4096) if t == 4 else WINO_MIN_KN[2])      # (F(4x4): 64 -> 64 included)
 
 
 def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     tile = _wino_tile(H, W)
+    if tile == 4 and B * (H // 4) * (W // 4) < WINO4_WGRAD_MIN_TILES:
+        tile = 2
     P = (tile + 2) ** 2
     T = B * (H // tile) * (W // tile)
     Tp = -(-T // 128) * 128

@@ -22,10 +22,10 @@ def wino_everywhere(request):
     """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path; F4x4: F(4x4, 3x3) wherever H and W
     are multiples of 4 (the other shapes of the lists then run F(2x2, 3x3) again)."""
     from scrabble_gan_amd import ops
-    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE)
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE = 32, 0, True, request.param
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES = {2: 32, 4: 32}, {2: 0, 4: 0}, True, request.param, 0
     yield ops
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE = old
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES = old
 
 
 @pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
@@ -144,7 +144,7 @@ def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
     ops = wino_everywhere
     from scrabble_gan_amd._lib import lib
     L = lib()
-    B, H, W, Cin, Cout = 4, 4, 20, 64, 128
+    B, H, W, Cin, Cout = 4, 4, 20, 128, 256
     g = torch.Generator(device=dev).manual_seed(11)
     x = torch.randn(B, H, W, Cin, device=dev, generator=g)
     w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)

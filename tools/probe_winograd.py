@@ -1,6 +1,6 @@
 """Direct vs Winograd-domain launches of the fp32 3x3 convolutions, per layer shape and direction (ms per launch):
 where the 16 / 36 product count pays for the two transform sweeps (-> ops.WINO_MIN_C / WINO_MIN_KN).
-    python tools/probe_winograd.py [--iters 5]            (SG_WINO_TILE=4: F(4x4, 3x3) where H and W allow)"""
+    python tools/probe_winograd.py [--iters 5]            (SG_WINO_TILE=2: F(2x2, 3x3) everywhere; default F(4x4, 3x3) where H and W allow)"""
 import argparse
 import os
 import sys
@@ -18,6 +18,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ("R.conv4 b256", 256, 8, 40, 256, 256), ("R.conv5 b256", 256, 4, 40, 256, 512), ("R.conv6 b256", 256, 4, 40, 512, 512),
     ("D.B2.conv1 b384", 384, 16, 80, 64, 512), ("G.B1.conv b16", 16, 8, 80, 256, 256), ("R.conv3 b32", 32, 8, 40, 128, 256),
     ("R.conv4 b32", 32, 8, 40, 256, 256), ("R.conv5 b32", 32, 4, 40, 256, 512), ("R.conv6 b32", 32, 4, 40, 512, 512),
+    ("D.B1.conv2 b384", 384, 32, 160, 64, 64), ("G.B3.conv b128", 128, 32, 160, 64, 64), ("R.conv2 b256", 256, 16, 80, 64, 128),
+    ("D.B2.conv1 b32", 32, 16, 80, 64, 512), ("D.B1.conv2 b32", 32, 32, 160, 64, 64),
 ]
 
 
@@ -39,7 +41,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    ops.WINO_MIN_C, ops.WINO_MIN_KN = 32, 0
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO4_WGRAD_MIN_TILES = {2: 32, 4: 32}, {2: 0, 4: 0}, 0
     print("%-18s | %21s | %21s | %21s   (ms direct / Winograd, ratio)" % ("layer", "fwd", "dgrad", "wgrad"))
     for name, B, H, W, Ci, Co in SHAPES:
         x = torch.randn(B, H, W, Ci, device=dev)

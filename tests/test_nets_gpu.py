@@ -186,8 +186,10 @@ def test_recognizer(setup, dev):
         close(loss, ref[:, 0], 1e-4, "ctc cost bn_training=%s" % bn_training)
         R.store.zero_grad()
         dx = R.backward(ctx, up.float().to(dev), want_dx=True, want_dw=True)
-        # dx crosses 4 max-pools and 7 ReLU masks: a near-tie resolved differently in fp32 moves single pixels
-        close(dx, xr.grad, 5e-3, "dx")
+        # dx crosses 4 max-pools and 7 ReLU masks: a near-tie resolved differently in fp32 moves single pixels (5e-3 with the direct
+        # and F(2x2) convolutions; 6.2e-3 measured once with F(4x4, 3x3), whose rounding error is ~5x F(2x2)'s -- still 1e-5 of the
+        # activations, but more near-ties fall on the other side; the weight gradients below keep their bounds)
+        close(dx, xr.grad, 1e-2, "dx")
         at = net_atol([v.grad for v in lv.values()])
         for k, v in lv.items():
             # training-mode BN over only B*H*W = 3*4*12 rows amplifies fp32 rounding of the batch statistics

@@ -302,7 +302,7 @@ def roofline_of(res, conv_dtype, world):
         traffic, traffic_src = committed_traffic(dom if dom == "igemm_wino" else "igemm", conv_dtype, res["B"] // world)
     except Exception:  # noqa: BLE001
         traffic, traffic_src = None, None
-    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the sixteen grouped Winograd-domain products of a 3x3 conv fwd / data-grad in one launch, "
+    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the 36 (F(4x4,3x3)) or 16 (F(2x2,3x3)) grouped Winograd-domain products of a 3x3 conv fwd / data-grad in one launch, "
                           "fp32 MFMA 32x32x2, executed FLOPs; the direct launches -- 1x1, 64-channel, strided -- are the family 'igemm')" if dom == "igemm_wino" else
                           "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)",
                    "bf16": "sg_igemm_bf16v2_kernel<BN, 2, RELU> / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; <= 32-filter convs stay fp32)",
@@ -447,8 +447,8 @@ def main():
         }
         if args.conv_dtype == "f32":
             line["flop_accounting"] = ("step_algorithmic_tflops / step_executed_tflops count DIRECT-form convolution FLOPs (the reference's tapes); in fp32 "
-                                       "mode the 3x3 convolutions over >= 128 channels run in the Winograd domain F(2x2,3x3) at 16/36 of that count "
-                                       "(conv_winograd.hip), so these rates may exceed the fp32 MFMA peak.  roofline.achieved and kernels.* count the "
+                                       "mode the 3x3 convolutions over >= 64 channels run in the Winograd domain -- F(4x4,3x3) at 9/36 of that count where H and W are "
+                                       "multiples of 4, F(2x2,3x3) at 16/36 otherwise (conv_winograd.hip) -- so these rates may exceed the fp32 MFMA peak.  roofline.achieved and kernels.* count the "
                                        "products the matrix cores EXECUTE (Winograd-domain products for those launches) over HIP-event time")
         line["config"]["hip_graph"] = bool(args.graph)
         line["config"]["fused_passes"] = True

@@ -1,22 +1,23 @@
-// Winograd-domain 3x3 convolutions, F(2x2, 3x3), fp32 (config c2 of BASELINE.json: the fp32 matrix rate bounds the step, so
-// the lever left is the NUMBER of products).  A stride-1 SAME 3x3 convolution over 2x2 output tiles
-//     Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2015; d = the 4x4 input patch of the tile, g = the 3x3 filter)
-// needs 16 products per tile, channel pair and output pair where the direct form needs 36: the sixteen "frequencies" are
-// sixteen independent [tiles x Cin] x [Cin x Cout] matrix products.  Three steps:
-//   1. input transform   x [B,H,W,C]           -> V [16][Tp][C]      (k_wino_in: adds only; the operand ReLU of the pre-activation
+// Winograd-domain 3x3 convolutions, fp32 (config c2 of BASELINE.json: the fp32 matrix rate bounds the step, so the lever left is
+// the NUMBER of products).  A stride-1 SAME 3x3 convolution over m x m output tiles
+//     Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2015; d = the (m+2) x (m+2) input patch of the tile, g = the filter)
+// needs (m+2)^2 products per tile, channel pair and m^2 outputs where the direct form needs 9 m^2: F(2x2, 3x3) 16 per 4 outputs
+// (first half of this file), F(4x4, 3x3) 36 per 16 outputs (second half; transforms generated into wino_f43.h).  The (m+2)^2
+// "frequencies" are independent [tiles x Cin] x [Cin x Cout] matrix products.  Three steps:
+//   1. input transform   x [B,H,W,C]           -> V [P][Tp][C]       (k_wino_in / k_w43_in; the operand ReLU of the pre-activation
 //                                                                     blocks is applied to the loaded values)
 //   2. ONE grouped launch of the DMA-fed implicit-GEMM kernel (conv_bf16v2.hip, fp32 operands, v_mfma_f32_32x32x2_f32): group f
-//      multiplies V[f] with the transformed filter U[f] = [N][K] into Mt[f] -- the same loop, tiles and epilogue as the direct
-//      fp32 launch, as a 1x1 convolution over 16 Tp "pixels";
-//   3. output transform  Mt [16][Tp][N]        -> y [B,H,W,N]        (k_wino_out: adds, then the conv entry points' epilogue --
+//      multiplies V[f] with the transformed filter U[f] = [N][K] into Mt[f] -- the same loop and epilogue as the direct fp32
+//      launch, as a 1x1 convolution over P Tp "pixels" on 128 x 128 tiles;
+//   3. output transform  Mt [P][Tp][N]         -> y [B,H,W,N]        (k_wino_out / k_w43_out: then the conv entry points' epilogue --
 //                                                                     bias, ReLU mask of the data-grad, accumulate, output ReLU).
 // The data-grad of such a convolution is the same convolution of dy with the spatially flipped filter and the channel roles
 // swapped, so it runs through the same three steps with U built from w [kh,kw,Cin,Cout] as it lies (flip = 1).
-// The transforms are HBM-bound sweeps (V and Mt are 4x the activation each); the products drop to 16 / 36 of the direct count.
-// Numerics: exact fp32 products and fp32 accumulation like the direct kernels; the transforms add at most four terms per
-// dimension and the filter transform scales by 1/2 and 1/4 (exact), so the error grows by a small constant factor over the
-// direct form (tests/test_winograd_gpu.py states the bound against the fp64 oracle).
-// Tiles: t = (b * H/2 + ty) * W/2 + tx, T = B H/2 W/2 of them, planes padded to Tp = T rounded up to 128 rows (the tile height of
+// The transforms are HBM-bound sweeps (V and Mt are 4x the activation each for m = 2, 2.25x for m = 4).
+// Numerics: exact fp32 products and fp32 accumulation like the direct kernels; the rounding inside the transforms is what differs
+// (measured against the fp64 oracle: F(2x2) <= 1e-6 of max |ref|, F(4x4) <= 1.3e-5; tests/test_winograd_gpu.py holds both to the
+// direct kernels' 2e-5).
+// Tiles: t = (b * H/m + ty) * W/m + tx, T = B H/m W/m of them, planes padded to Tp = T rounded up to 128 rows (the tile height of
 // the grouped product: a tile never straddles two frequencies; 128 rather than 256 rows because the 8-way shard batch has
 // T = 320 on the 4x20 layers); the pad rows are never written nor read back.
 #include "sg_conv2.h"

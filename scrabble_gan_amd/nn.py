@@ -234,7 +234,12 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     p, g = S.p, S.g
     H, W = x.shape[1], x.shape[2]
     pooled_short = xp is not None
-    if want_dw and pooled_short:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
+    # Small launches with the side stream on: the block's three weight-grad launches go to the side stream TOGETHER, behind ONE
+    # event wait placed after conv2's data-grad (hipStreamWaitEvent costs the host 0.29 ms per call on this stack -- 37 of them were
+    # 11 of the 24 ms it takes to queue a shard-size step, tools/host_profile.py); the side stream still runs beside the block's
+    # remaining data-grads and the next block's.
+    one_join = want_dw and ops.side_enabled() and dout.shape[0] <= ops.SIDE_MAX_BATCH
+    if want_dw and pooled_short and not one_join:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
         with ops.side_stream(xp, dout, wscale):
             ops.conv2d_bwd_weight(xp, dout, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     if is_last:
@@ -243,7 +248,7 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
         d_c2 = ops.avgpool2_bwd_operands(dout, wscale, want_dw)
     else:
         d_c2 = ops.avgpool2_bwd(dout)
-    if want_dw:          # (weight gradients are leaves of the sweep: side stream, see ops.side_stream)
+    if want_dw and not one_join:          # (weight gradients are leaves of the sweep: side stream, see ops.side_stream)
         with ops.side_stream(c1, x, d_c2, wscale):
             ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
             if not pooled_short:
@@ -252,7 +257,15 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     cin, cout = x.shape[-1], c1.shape[-1]
     d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True),
                                amax_scale=wscale)
-    if want_dw:
+    if one_join:
+        with ops.side_stream(x, c1, xp, dout, d_c2, d_c1, wscale):
+            if pooled_short:
+                ops.conv2d_bwd_weight(xp, dout, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
+            ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
+            if not pooled_short:
+                ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
+            ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
+    elif want_dw:
         with ops.side_stream(x, d_c1, wscale):
             ops.conv2d_bwd_weight(x, d_c1, g[pre + ".conv1.w"], relu_in=True, db=g[pre + ".conv1.b"], sample_scale=wscale)
     if not want_dx:

@@ -1,12 +1,13 @@
-"""Winograd-domain fp32 3x3 convolutions (scrabble_gan_amd/csrc/conv_winograd.hip; round 3) against the fp64 oracle.
+"""Winograd-domain fp32 3x3 convolutions (scrabble_gan_amd/csrc/conv_winograd.hip; round 3) against the fp64 oracle, both forms:
+F(4x4, 3x3) (the default wherever H and W are multiples of 4) and F(2x2, 3x3).
 
-The path replaces the direct implicit-GEMM launch of the stride-1 SAME 3x3 convolutions over >= 512 reduction channels in fp32
-mode -- and, with smaller gains, those down to 128 channels (ops._wino_ok) -- (resnet_ops.py:65,98,103 of the reference: the ResNet
-blocks' convolutions) -- same contract, 16 / 36 of the multiplies.
-Tolerances (max |got - ref| <= tol * max |ref|): 2e-5 against the fp64 oracle, the bound the direct fp32 kernels are held to
-(tests/test_fullsize_gpu.py); the measured error is printed -- the transforms add <= 4 terms per dimension, so the Winograd
-form's rounding error is a small multiple of the direct form's.  Launch-geometry rows of tests/test_fullsize_gpu.py (f32 mode) and
-the whole-network / train_step tests run through this path too (ops._wino_ok)."""
+The path replaces the direct implicit-GEMM launch of the stride-1 SAME 3x3 convolutions over >= 64 channels in fp32 mode
+(ops._wino_ok; resnet_ops.py:65,98,103 of the reference: the ResNet blocks' convolutions; net_architecture.py:28-49: the
+recognizer's) -- same contract, 9 / 36 or 16 / 36 of the multiplies.  Tolerances (max |got - ref| <= tol * max |ref|): 2e-5 for
+y / dx and 1e-4 for dW / db against the fp64 oracle, the bounds the direct fp32 kernels are held to (tests/test_fullsize_gpu.py);
+the measured errors are printed (F(2x2) <= 1e-6, F(4x4) <= 5e-6 here and <= 1.3e-5 against the direct kernels at launch
+geometry).  The launch-geometry rows of tests/test_fullsize_gpu.py (f32 mode) and the whole-network / train_step tests run
+through the default path too."""
 import math
 
 import pytest

@@ -22,6 +22,7 @@
 // T = 320 on the 4x20 layers); the pad rows are never written nor read back.
 #include "sg_conv2.h"
 #include "wino_f43.h"
+#include <stdlib.h>
 
 #define WINO_F 16
 
@@ -253,9 +254,13 @@ __global__ __launch_bounds__(256) void k_wino_dw(const float* __restrict__ dU, f
 // columns, then along the rows.  Same kernels-and-planes structure as above with 36 planes; tiles t = (b * H/4 + ty) * W/4 + tx.
 // ==========================================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
-__device__ __forceinline__ void st4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
-__device__ __forceinline__ v4f relu4v(v4f v) { return __builtin_elementwise_max(v, (v4f){0.f, 0.f, 0.f, 0.f}); }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// VT = the channels one thread carries through a tile's transform: v4f (16-byte accesses, 144 live registers for the 6x6 patch: two
+// waves per SIMD) or v2f (8-byte accesses, half the registers, twice the waves) -- SG_WINO_VEC picks, measured in DESIGN 3e
+template <typename VT> __device__ __forceinline__ VT ldv(const float* p) { return *reinterpret_cast<const VT*>(p); }
+template <typename VT> __device__ __forceinline__ void stv(float* p, VT v) { *reinterpret_cast<VT*>(p) = v; }
+template <typename VT> __device__ __forceinline__ VT zerov() { VT z; for (int i = 0; i < (int)(sizeof(VT) / 4); ++i) z[i] = 0.f; return z; }
+template <typename VT> __device__ __forceinline__ VT reluv(VT v) { return __builtin_elementwise_max(v, zerov<VT>()); }
 
 __global__ __launch_bounds__(256) void k_w43_filter(const float* __restrict__ in, float* __restrict__ U, long NK, int flip) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < NK; e += (long)gridDim.x * 256) {
@@ -276,142 +281,153 @@ __global__ __launch_bounds__(256) void k_w43_filter(const float* __restrict__ in
   }
 }
 
-template <bool RELU>
+template <bool RELU, typename VT>
 __global__ __launch_bounds__(256) void k_w43_in(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, long T, long Tp) {
-  const int C4 = C >> 2, H4 = H >> 2, W4 = W >> 2;
-  const long items = T * C4;
+  constexpr int VW = sizeof(VT) / 4;
+  const int CV = C / VW, H4 = H >> 2, W4 = W >> 2;
+  const long items = T * CV;
   const size_t plane = (size_t)Tp * C;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
-    const long t = it / C4;
-    const int c = (int)(it - t * C4) * 4;
+    const long t = it / CV;
+    const int c = (int)(it - t * CV) * VW;
     const int tx = (int)(t % W4);
     const long r = t / W4;
     const int ty = (int)(r % H4);
     const long b = r / H4;
-    v4f u[6][6];                                   // columns transformed: u[i][j] = sum_a BT[i][a] d[a][j]
+    VT u[6][6];                                    // columns transformed: u[i][j] = sum_a BT[i][a] d[a][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int ix = 4 * tx - 1 + j;
-      v4f d[6];
+      VT d[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int iy = 4 * ty - 1 + a;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(x + ((size_t)(b * H + iy) * W + ix) * C + c);
-        d[a] = RELU ? relu4v(v) : v;
+        VT v = zerov<VT>();
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldv<VT>(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        d[a] = RELU ? reluv<VT>(v) : v;
       }
       w43_bt(d[0], d[1], d[2], d[3], d[4], d[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
     }
     float* out = V + (size_t)t * C + c;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      v4f o0, o1, o2, o3, o4, o5;
+      VT o0, o1, o2, o3, o4, o5;
       w43_bt(u[i][0], u[i][1], u[i][2], u[i][3], u[i][4], u[i][5], o0, o1, o2, o3, o4, o5);
       float* q = out + (size_t)(i * 6) * plane;
-      st4(q, o0); st4(q + plane, o1); st4(q + 2 * plane, o2); st4(q + 3 * plane, o3); st4(q + 4 * plane, o4); st4(q + 5 * plane, o5);
+      stv<VT>(q, o0); stv<VT>(q + plane, o1); stv<VT>(q + 2 * plane, o2); stv<VT>(q + 3 * plane, o3); stv<VT>(q + 4 * plane, o4); stv<VT>(q + 5 * plane, o5);
     }
   }
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256) void k_w43_out(const float* __restrict__ Mt, float* __restrict__ y, const float* __restrict__ bias,
                                                  const float* __restrict__ bias2, const float* __restrict__ mask, int H, int W, int N, long T,
                                                  long Tp, int flags) {
-  const int N4 = N >> 2, H4 = H >> 2, W4 = W >> 2;
+  constexpr int VW = sizeof(VT) / 4;
+  const int N4 = N / VW, H4 = H >> 2, W4 = W >> 2;
   const long items = T * N4;
   const size_t plane = (size_t)Tp * N;
   const bool accum = (flags & SG_ACCUM) != 0, relu_out = (flags & SG_RELU_OUT) != 0;
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
     const long t = it / N4;
-    const int n = (int)(it - t * N4) * 4;
+    const int n = (int)(it - t * N4) * VW;
     const int tx = (int)(t % W4);
     const long r = t / W4;
     const int ty = (int)(r % H4);
     const long b = r / H4;
     const float* src = Mt + (size_t)t * N + n;
-    v4f q[4][6];                                   // columns reduced: q[i][j] = sum_a AT[i][a] m[a][j]
+    VT q[4][6];                                   // columns reduced: q[i][j] = sum_a AT[i][a] m[a][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      v4f m[6];
+      VT m[6];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) m[a] = ld4(src + (size_t)(a * 6 + j) * plane);
+      for (int a = 0; a < 6; ++a) m[a] = ldv<VT>(src + (size_t)(a * 6 + j) * plane);
       w43_at(m[0], m[1], m[2], m[3], m[4], m[5], q[0][j], q[1][j], q[2][j], q[3][j]);
     }
-    v4f bs = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bs += ld4(bias + n);
-    if (bias2) bs += ld4(bias2 + n);
+    VT bs = zerov<VT>();
+    if (bias) bs += ldv<VT>(bias + n);
+    if (bias2) bs += ldv<VT>(bias2 + n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v4f o[4];
+      VT o[4];
       w43_at(q[i][0], q[i][1], q[i][2], q[i][3], q[i][4], q[i][5], o[0], o[1], o[2], o[3]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v4f v = o[j] + bs;
+        VT v = o[j] + bs;
         const size_t idx = ((size_t)(b * H + 4 * ty + i) * W + 4 * tx + j) * N + n;
         if (mask) {
-          const v4f k = ld4(mask + idx);
-          if (k.x <= 0.f) v.x = 0.f;
-          if (k.y <= 0.f) v.y = 0.f;
-          if (k.z <= 0.f) v.z = 0.f;
-          if (k.w <= 0.f) v.w = 0.f;
+          const VT k = ldv<VT>(mask + idx);
+#pragma unroll
+          for (int e = 0; e < VW; ++e)
+            if (k[e] <= 0.f) v[e] = 0.f;
         }
-        if (accum) v += ld4(y + idx);
-        if (relu_out) v = relu4v(v);
-        st4(y + idx, v);
+        if (accum) v += ldv<VT>(y + idx);
+        if (relu_out) v = reluv<VT>(v);
+        stv<VT>(y + idx, v);
       }
     }
   }
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256) void k_w43_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
                                                 float* __restrict__ db, int H, int W, int N, long T, long Tp) {
-  __shared__ float4 red[256];
-  const int N4 = N >> 2, H4 = H >> 2, W4 = W >> 2;
+  constexpr int VW = sizeof(VT) / 4;
+  __shared__ float red[256 * VW];
+  const int N4 = N / VW, H4 = H >> 2, W4 = W >> 2;
   const long items = T * N4;
   const size_t plane = (size_t)Tp * N;
   const bool fixed_col = ((long)gridDim.x * 256) % N4 == 0;          // (see k_wino_dy)
-  v4f bsum = {0.f, 0.f, 0.f, 0.f};
+  VT bsum = zerov<VT>();
   for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
     const long t = it / N4;
-    const int n = (int)(it - t * N4) * 4;
+    const int n = (int)(it - t * N4) * VW;
     const int tx = (int)(t % W4);
     const long r = t / W4;
     const int ty = (int)(r % H4);
     const long b = r / H4;
     const float sc = sample_scale ? sample_scale[b] : 1.f;
-    v4f rr[6][4];                                  // columns expanded: rr[i][j] = sum_a A[i][a] d[a][j]
-    v4f s4 = {0.f, 0.f, 0.f, 0.f};
+    VT rr[6][4];                                  // columns expanded: rr[i][j] = sum_a A[i][a] d[a][j]
+    VT s4 = zerov<VT>();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v4f d[4];
+      VT d[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        d[a] = ld4(dy + ((size_t)(b * H + 4 * ty + a) * W + 4 * tx + j) * N + n) * sc;
+        d[a] = ldv<VT>(dy + ((size_t)(b * H + 4 * ty + a) * W + 4 * tx + j) * N + n) * sc;
         s4 += d[a];
       }
       w43_a(d[0], d[1], d[2], d[3], rr[0][j], rr[1][j], rr[2][j], rr[3][j], rr[4][j], rr[5][j]);
     }
     if (db) {
       if (fixed_col) bsum += s4;
-      else { atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w); }
+      else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) atomicAdd(db + n + e, s4[e]);
+      }
     }
     float* out = Qt + (size_t)t * N + n;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      v4f o0, o1, o2, o3, o4, o5;
+      VT o0, o1, o2, o3, o4, o5;
       w43_a(rr[i][0], rr[i][1], rr[i][2], rr[i][3], o0, o1, o2, o3, o4, o5);
       float* q = out + (size_t)(i * 6) * plane;
-      st4(q, o0); st4(q + plane, o1); st4(q + 2 * plane, o2); st4(q + 3 * plane, o3); st4(q + 4 * plane, o4); st4(q + 5 * plane, o5);
+      stv<VT>(q, o0); stv<VT>(q + plane, o1); stv<VT>(q + 2 * plane, o2); stv<VT>(q + 3 * plane, o3); stv<VT>(q + 4 * plane, o4); stv<VT>(q + 5 * plane, o5);
     }
   }
   if (db && fixed_col) {
-    red[threadIdx.x] = make_float4(bsum.x, bsum.y, bsum.z, bsum.w);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) red[threadIdx.x * VW + e] = bsum[e];
     __syncthreads();
     const int per = N4 < 256 ? N4 : 256;
     if ((int)threadIdx.x < per) {
-      float4 s4 = red[threadIdx.x];
-      for (int k = threadIdx.x + per; k < 256; k += per) s4 = f4_add(s4, red[k]);
-      const int n = (int)((((long)blockIdx.x * 256 + threadIdx.x) % N4) * 4);
-      atomicAdd(db + n, s4.x); atomicAdd(db + n + 1, s4.y); atomicAdd(db + n + 2, s4.z); atomicAdd(db + n + 3, s4.w);
+      const int n = (int)((((long)blockIdx.x * 256 + threadIdx.x) % N4) * VW);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        float acc = 0.f;
+        for (int k = threadIdx.x; k < 256; k += per) acc += red[k * VW + e];
+        atomicAdd(db + n + e, acc);
+      }
     }
   }
 }
@@ -441,6 +457,10 @@ __global__ __launch_bounds__(256) void k_w43_dw(const float* __restrict__ dU, fl
 // C-ABI (include/scrabble_hip.h).  tile = 2: F(2x2, 3x3), 16 planes, H and W even;  tile = 4: F(4x4, 3x3), 36 planes, H % 4 == W % 4 == 0.
 // ------------------------------------------------------------------------------------------
 static inline int wino_planes(int tile) { return (tile + 2) * (tile + 2); }
+static int wino_vec() {
+  static const int v = getenv("SG_WINO_VEC") ? atoi(getenv("SG_WINO_VEC")) : 4;
+  return v == 2 ? 2 : 4;
+}
 static bool wino_geom_ok(int B, int H, int W, int tile) {
   return (tile == 2 || tile == 4) && B > 0 && H > 0 && W > 0 && !(H % tile) && !(W % tile);
 }
@@ -477,8 +497,14 @@ extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int 
     if (relu) SG_KERNEL(k_wino_in<true>, grid, block, 0, s, x, V, H, W, C, T, Tp);
     else SG_KERNEL(k_wino_in<false>, grid, block, 0, s, x, V, H, W, C, T, Tp);
   } else {
-    if (relu) SG_KERNEL(k_w43_in<true>, grid, block, 0, s, x, V, H, W, C, T, Tp);
-    else SG_KERNEL(k_w43_in<false>, grid, block, 0, s, x, V, H, W, C, T, Tp);
+    if (wino_vec() == 2) {
+      const dim3 grid2(sg_grid_for(T * (C / 2), 256));
+      if (relu) SG_KERNEL((k_w43_in<true, v2f>), grid2, block, 0, s, x, V, H, W, C, T, Tp);
+      else SG_KERNEL((k_w43_in<false, v2f>), grid2, block, 0, s, x, V, H, W, C, T, Tp);
+    } else {
+      if (relu) SG_KERNEL((k_w43_in<true, v4f>), grid, block, 0, s, x, V, H, W, C, T, Tp);
+      else SG_KERNEL((k_w43_in<false, v4f>), grid, block, 0, s, x, V, H, W, C, T, Tp);
+    }
   }
   return sg_launch_status();
 }
@@ -510,7 +536,8 @@ extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, cons
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
   if (tile == 2) SG_KERNEL(k_wino_out, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
-  else SG_KERNEL(k_w43_out, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+  else if (wino_vec() == 2) SG_KERNEL(k_w43_out<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+  else SG_KERNEL(k_w43_out<v4f>, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
   return sg_launch_status();
 }
 
@@ -555,7 +582,8 @@ extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sampl
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
   if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
-  else SG_KERNEL(k_w43_dy, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  else if (wino_vec() == 2) SG_KERNEL(k_w43_dy<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  else SG_KERNEL(k_w43_dy<v4f>, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
   return sg_launch_status();
 }
 

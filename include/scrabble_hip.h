@@ -104,9 +104,12 @@ int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* ma
  *      db += when non-null, sample_scale [B] nullable, SG_RELU_IN on x): dU[f] = V[f]^T Qt[f] over the tiles with
  *      Qt = A dy A^T (sg_wino_grad_input: rows scaled by sample_scale[b], db += their column sums), then dw += G^T dU G
  *      (sg_wino_filter_grad).  sg_wino_wgrad_gemm overwrites dU [P][Cin][Cout]; partial sums of the tile chunks meet through
- *      float atomics (one chunk in deterministic mode).  Workspace: sg_wino_wgrad_workspace_bytes = V | Qt | dU. */
+ *      float atomics (one chunk in deterministic mode).  db_scratch (nullable): 64 x N floats of scratch through which the bias
+ *      gradient's column sums are folded (short atomic chains); null: every workgroup adds into db itself.
+ *      Workspace: sg_wino_wgrad_workspace_bytes = V | Qt | dU | those 64 x Cout floats. */
 long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
-int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, int tile, void* stream);
+int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch,
+                       int B, int H, int W, int N, int tile, void* stream);
 int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, void* stream);
 int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, int tile, void* stream);
 int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale,

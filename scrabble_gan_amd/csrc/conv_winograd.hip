@@ -161,8 +161,21 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ Mt, 
 //      conv_wgrad.hip in its grouped form), dW = G^T dU G.
 // gradient transform: dy [B,H,W,N] -> Qt [16][Tp][N], rows scaled by sample_scale[b] (nullable); db (nullable) += column sums of
 // the scaled dy.  One thread = one tile x four channels; A = [1 0; 1 1; 1 -1; 0 -1].
+// db_part (nullable): WINO_DB_PARTS x N scratch rows, zeroed by the caller -- block b adds its column sums to row b % WINO_DB_PARTS and
+// k_wino_db_finish folds the rows into db: chains of gridDim / 64 adders per address instead of gridDim (2 048 same-address float
+// atomics cost 0.15 ms per launch: the gradient transform ran 2.7x slower than the input transform of the same tensor)
+#define WINO_DB_PARTS 64
+__global__ __launch_bounds__(256) void k_wino_db_finish(const float* __restrict__ db_part, float* __restrict__ db, int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int r = 0; r < WINO_DB_PARTS; ++r) acc += db_part[(size_t)r * N + n];
+  db[n] += acc;
+}
+
 __global__ __launch_bounds__(256) void k_wino_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
-                                                 float* __restrict__ db, int H, int W, int N, long T, long Tp) {
+                                                 float* __restrict__ db_in, float* __restrict__ db_part, int H, int W, int N, long T, long Tp) {
+  float* const db = db_in ? (db_part ? db_part + (size_t)(blockIdx.x % WINO_DB_PARTS) * N : db_in) : nullptr;
   __shared__ float4 red[256];
   const int N4 = N >> 2, H2 = H >> 1, W2 = W >> 1;
   const long items = T * N4;
@@ -371,7 +384,8 @@ __global__ __launch_bounds__(256) void k_w43_out(const float* __restrict__ Mt, f
 
 template <typename VT>
 __global__ __launch_bounds__(256) void k_w43_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
-                                                float* __restrict__ db, int H, int W, int N, long T, long Tp) {
+                                                float* __restrict__ db_in, float* __restrict__ db_part, int H, int W, int N, long T, long Tp) {
+  float* const db = db_in ? (db_part ? db_part + (size_t)(blockIdx.x % WINO_DB_PARTS) * N : db_in) : nullptr;
   constexpr int VW = sizeof(VT) / 4;
   __shared__ float red[256 * VW];
   const int N4 = N / VW, H4 = H >> 2, W4 = W >> 2;
@@ -568,22 +582,26 @@ extern "C" int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, cons
   return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, tile, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// ---- weight gradient: workspace = V [planes][Tp][Cin] | Qt [planes][Tp][Cout] | dU [planes][Cin][Cout]
+// ---- weight gradient: workspace = V [planes][Tp][Cin] | Qt [planes][Tp][Cout] | dU [planes][Cin][Cout] | bias-gradient partial rows [64][Cout]
 extern "C" long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile) {
   if (!wino_geom_ok(B, H, W, tile) || Cin <= 0 || Cout <= 0) return 0;
   const long Tp = wino_tp(wino_tiles(B, H, W, tile));
-  return (long)sizeof(float) * wino_planes(tile) * (Tp * ((long)Cin + Cout) + (long)Cin * Cout);
+  return (long)sizeof(float) * (wino_planes(tile) * (Tp * ((long)Cin + Cout) + (long)Cin * Cout) + (long)WINO_DB_PARTS * Cout);
 }
 
-extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, int B, int H, int W, int N, int tile,
-                                  void* stream) {
+extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H, int W,
+                                  int N, int tile, void* stream) {
   if (!dy || !Qt) return SG_ERR_ARG;
   if (!wino_geom_ok(B, H, W, tile) || (N & 3) || N <= 0) return SG_ERR_UNSUPPORTED;
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
+  hipStream_t s = (hipStream_t)stream;
   const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
-  if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
-  else if (wino_vec() == 2) SG_KERNEL(k_w43_dy<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
-  else SG_KERNEL(k_w43_dy<v4f>, grid, block, 0, (hipStream_t)stream, dy, Qt, sample_scale, db, H, W, N, T, Tp);
+  float* part = db ? db_scratch : nullptr;       // (db_scratch: WINO_DB_PARTS x N floats; null -> every block adds into db itself)
+  if (part && hipMemsetAsync(part, 0, sizeof(float) * (size_t)WINO_DB_PARTS * N, s) != hipSuccess) return SG_ERR_LAUNCH;
+  if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
+  else if (wino_vec() == 2) SG_KERNEL(k_w43_dy<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
+  else SG_KERNEL(k_w43_dy<v4f>, grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
+  if (part) SG_KERNEL(k_wino_db_finish, dim3(sg_cdiv(N, 256)), dim3(256), 0, s, part, db, N);
   return sg_launch_status();
 }
 
@@ -626,7 +644,7 @@ extern "C" int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float*
   float* dU = Qt + (size_t)F * Tp * Cout;
   int rc = sg_wino_input(x, V, B, H, W, Cin, (flags & SG_RELU_IN) != 0, tile, stream);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, B, H, W, Cout, tile, stream);
+  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, dU + (size_t)F * Cin * Cout, B, H, W, Cout, tile, stream);
   if (rc != SG_OK) return rc;
   rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, tile, stream);
   if (rc != SG_OK) return rc;

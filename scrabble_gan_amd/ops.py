@@ -789,7 +789,7 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     P = (tile + 2) ** 2
     T = B * (H // tile) * (W // tile)
     Tp = -(-T // 128) * 128
-    nbytes = 4 * P * (Tp * (Cin + Cout) + Cin * Cout)          # = sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)
+    nbytes = 4 * (P * (Tp * (Cin + Cout) + Cin * Cout) + 64 * Cout)          # = sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)
     ws = _wino_workspace(nbytes, x)
     V = ws.data_ptr()
     Qt = V + 4 * P * Tp * Cin
@@ -802,7 +802,7 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * (Cin + Cout)
         call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), tile, s)
-        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), B, H, W, Cout, tile, s)
+        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), dU + 4 * P * Cin * Cout, B, H, W, Cout, tile, s)
     with _timed("wgrad_wino", 2.0 * P * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
         if PROFILER is not None and PROFILER.wants("wgrad_wino"):
             PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * P * (T * (Cin + Cout) + Cin * Cout)

@@ -65,7 +65,7 @@ def test_fp32_emulation_of_the_f43_pipeline_stays_inside_the_stated_tolerance():
 
 def test_workspace_arithmetic_of_the_c_abi():
     """sg_wino_plane_rows / sg_wino_workspace_bytes / sg_wino_wgrad_workspace_bytes are pure host functions: planes of
-    ceil(T / 128) * 128 rows, V | Mt (| dU) back to back; shapes the tile size does not divide are refused with 0."""
+    ceil(T / 128) * 128 rows, V | Mt (or V | Qt | dU | 64 bias-gradient rows) back to back; shapes the tile size does not divide are refused with 0."""
     from scrabble_gan_amd._lib import lib
     L = lib()
     for tile in (2, 4):
@@ -75,7 +75,7 @@ def test_workspace_arithmetic_of_the_c_abi():
             Tp = -(-T // 128) * 128
             assert L.sg_wino_plane_rows(B, H, W, tile) == Tp
             assert L.sg_wino_workspace_bytes(B, H, W, Ci, Co, tile) == 4 * P * Tp * (Ci + Co)
-            assert L.sg_wino_wgrad_workspace_bytes(B, H, W, Ci, Co, tile) == 4 * P * (Tp * (Ci + Co) + Ci * Co)
+            assert L.sg_wino_wgrad_workspace_bytes(B, H, W, Ci, Co, tile) == 4 * (P * (Tp * (Ci + Co) + Ci * Co) + 64 * Co)
     assert L.sg_wino_plane_rows(2, 6, 8, 4) == 0 and L.sg_wino_plane_rows(2, 6, 8, 2) == 128
     assert L.sg_wino_workspace_bytes(2, 3, 8, 64, 128, 2) == 0 and L.sg_wino_workspace_bytes(2, 4, 8, 64, 128, 3) == 0
 

@@ -167,7 +167,7 @@ def test_c_abi_entry_points_and_workspace_contract(dev, wino_everywhere):
     assert L.sg_conv2d_bwd_data_wino(dy.data_ptr(), ub.data_ptr(), x.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, 0, tile, ws.data_ptr(), nbytes, s) == 0
     assert torch.equal(dx, ops.conv2d_bwd_data(dy, w, (H, W), mask=x))
     nb2 = L.sg_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout, tile)
-    assert nb2 == nbytes + 4 * P * Cin * Cout
+    assert nb2 == nbytes + 4 * P * Cin * Cout + 4 * 64 * Cout
     ws2 = torch.empty(nb2, device=dev, dtype=torch.uint8)
     dw, db = torch.zeros_like(w), torch.zeros_like(b)
     assert L.sg_conv2d_bwd_weight_wino(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), None, B, H, W, Cin, Cout, 1, tile, ws2.data_ptr(), nb2, s) == 0

@@ -106,11 +106,13 @@ int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* ma
  *      (sg_wino_filter_grad).  sg_wino_wgrad_gemm overwrites dU [P][Cin][Cout]; partial sums of the tile chunks meet through
  *      float atomics (one chunk in deterministic mode).  db_scratch (nullable): 64 x N floats of scratch through which the bias
  *      gradient's column sums are folded (short atomic chains); null: every workgroup adds into db itself.
+ *      sg_wino_wgrad_gemm's v_plane_rows: rows between two planes of V (0 = this batch's Tp) -- the forward launch's V, kept by the
+ *      host, serves the weight gradient of a batch slice without a second transform sweep.
  *      Workspace: sg_wino_wgrad_workspace_bytes = V | Qt | dU | those 64 x Cout floats. */
 long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
 int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch,
                        int B, int H, int W, int N, int tile, void* stream);
-int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, void* stream);
+int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, long v_plane_rows, void* stream);
 int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, int tile, void* stream);
 int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale,
                               int B, int H, int W, int Cin, int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream);

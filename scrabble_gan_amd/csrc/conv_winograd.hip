@@ -606,10 +606,13 @@ extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sampl
 }
 
 // dU [planes][K][N] = sum over the T tiles of V[f]^T Qt[f] (dU is overwritten)
-extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, void* stream) {
+// v_plane_rows: rows between two planes of V (0 = Tp of this batch; larger when V is a batch slice of a transform made for a bigger batch)
+extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, long v_plane_rows,
+                                  void* stream) {
   if (!V || !Qt || !dU) return SG_ERR_ARG;
   if (!wino_geom_ok(B, H, W, tile) || (K & 3) || (N & 3) || K <= 0 || N <= 0) return SG_ERR_UNSUPPORTED;
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
+  if (v_plane_rows != 0 && v_plane_rows < T) return SG_ERR_ARG;
   if (T >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
   const int F = wino_planes(tile);
   hipStream_t s = (hipStream_t)stream;
@@ -619,7 +622,7 @@ extern "C" int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, in
   a.Bn = (int)T; a.Hp = 1; a.Wp = 1; a.Cp = K; a.p_sy = 1; a.p_sx = 1;
   a.Hq = 1; a.Wq = 1; a.Cq = N; a.q_sy = 1; a.q_sx = 1; a.Hg = 1; a.Wg = 1;
   a.ntaps = F; a.flags = 0;
-  a.p_plane = Tp * K;
+  a.p_plane = (v_plane_rows ? v_plane_rows : Tp) * K;
   a.q_plane = Tp * N;
   return sg_launch_wgrad(a, s);
 }
@@ -646,7 +649,7 @@ extern "C" int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float*
   if (rc != SG_OK) return rc;
   rc = sg_wino_grad_input(dy, Qt, sample_scale, db, dU + (size_t)F * Cin * Cout, B, H, W, Cout, tile, stream);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, tile, stream);
+  rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, tile, 0, stream);
   if (rc != SG_OK) return rc;
   return sg_wino_filter_grad(dU, dw, Cin, Cout, tile, stream);
 }

@@ -333,6 +333,7 @@ def train_step(epoch_idx, batch_idx, batch_per_epoch, images, labels, discrimina
             red.wait(h)
         generator_optimizer.apply_flat(G.store)
 
+    ops.end_step()
     if not sync:
         return scalars
     out = StepScalars(scalars, (epoch_idx, batch_idx, batch_per_epoch) if verbose else None)

@@ -584,9 +584,19 @@ def _amax_get(t: torch.Tensor, scale=None, need_scaled: bool = False):
 def new_step() -> None:
     _TWINS.clear()
     _AMAX_POOL["buf"] = None
+    _WINO_V["map"].clear()
+    _WINO_V["on"] = WINO_KEEP_V
+
+
+def end_step() -> None:
+    """The step's backward sweeps are queued: the kept Winograd transforms are released (and launches outside a step keep none)."""
+    _WINO_V["map"].clear()
+    _WINO_V["on"] = False
 
 
 def _touch(t) -> None:
+    if t is not None and _WINO_V["map"]:
+        _WINO_V["map"].pop(t.untyped_storage().data_ptr(), None)
     if t is not None and _TWINS:
         k = t.untyped_storage().data_ptr()
         _TWINS.pop(k, None)
@@ -709,6 +719,27 @@ WINO_MIN_C = {2: int(_os.environ.get("SG_WINO_MIN_C", "128")), 4: int(_os.enviro
 WINO_MIN_KN = {2: int(_os.environ.get("SG_WINO_MIN_KN", "32768")), 4: int(_os.environ.get("SG_WINO4_MIN_KN", "16384"))}   # ... and their product at least this
 WINO4_WGRAD_MIN_TILES = 128     # weight-grad: below this many 4x4 tiles the 36 reductions are too short (B = 16 on the 4x20 layers) -> F(2x2)
 _WINO_WS = {}              # raw stream handle -> scratch buffer (V and Mt of the launch in flight on that stream)
+# The forward launch's transformed input V is exactly what the weight gradient of the same convolution needs: inside a train_step
+# (new_step() ... end_step()) forward launches keep V in a tensor of their own (2.25x the layer input for F(4x4)) and the weight-grad
+# finds it again through the input's storage -- a batch slice of the input maps to a row range of every plane -- instead of
+# transforming relu(x) a second time.
+WINO_KEEP_V = _os.environ.get("SG_WINO_KEEP_V", "1") == "1"
+_WINO_V = {"on": False, "map": {}}      # map: storage pointer of x -> (x, relu_in, tile, V [P * Tp * K], Tp)
+
+
+def _wino_v_get(x: torch.Tensor, relu_in: bool, tile: int):
+    """-> (pointer of the first row of x's tiles in plane 0, rows between planes) or None"""
+    e = _WINO_V["map"].get(x.untyped_storage().data_ptr())
+    if e is None or e[1] != relu_in or e[2] != tile or e[0].shape[1:] != x.shape[1:]:
+        return None
+    per = x.shape[1] * x.shape[2] * x.shape[3]
+    off = x.storage_offset() - e[0].storage_offset()
+    if off < 0 or off % per or off // per + x.shape[0] > e[0].shape[0]:
+        return None
+    t0 = (off // per) * (x.shape[1] // tile) * (x.shape[2] // tile)
+    if e[5] != _stream():                   # read on another stream than the one it was made on (weight-grads on the sweep's side stream)
+        e[3].record_stream(torch.cuda.current_stream())
+    return e[3].data_ptr() + 4 * t0 * x.shape[3], e[4]
 
 
 def _wino_tile(H: int, W: int) -> int:
@@ -746,10 +777,25 @@ def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
     T = B * (H // tile) * (W // tile)
     Tp = -(-T // 128) * 128                 # = sg_wino_plane_rows(B, H, W, tile)
     nbytes = 4 * P * Tp * (K + N)           # = sg_wino_workspace_bytes(B, H, W, K, N, tile)
-    ws = _wino_workspace(nbytes, a)
-    V = ws.data_ptr()
-    Mt = V + 4 * P * Tp * K
     s = _stream()
+    keep = (fwd and _WINO_V["on"] and a.storage_offset() == 0 and _wino_wgrad_ok(K, N, 3, 3, True, H, W)
+            and (tile == 2 or T >= WINO4_WGRAD_MIN_TILES))
+    if keep:                                # V in a tensor of its own (the weight gradient reads it again), Mt in the stream's scratch
+        Vt = torch.empty(P * Tp * K, device=a.device, dtype=torch.float32)
+        if len(_WINO_V["map"]) > 256:
+            _WINO_V["map"].clear()
+        _WINO_V["map"][a.untyped_storage().data_ptr()] = (a, bool(relu_in), tile, Vt, Tp, s)
+        V = Vt.data_ptr()
+        Mt = _wino_workspace(4 * P * Tp * N, a).data_ptr()
+        if PROFILER is None:
+            call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), tile, s)
+            call("sg_wino_gemm", V, _p(u), Mt, B, H, W, K, N, tile, s)
+            call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), None, B, H, W, N, flags, tile, s)
+            return
+    else:
+        ws = _wino_workspace(nbytes, a)
+        V = ws.data_ptr()
+        Mt = V + 4 * P * Tp * K
     if PROFILER is None:                    # one call for the three launches (the host queues a shard-size step in half its GPU time)
         if fwd:
             call("sg_conv2d_fwd_wino", _p(a), _p(u), _p(bias), _p(bias2), _p(out), B, H, W, K, N, flags | (1 if relu_in else 0), tile, V, nbytes, s)
@@ -795,18 +841,23 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     Qt = V + 4 * P * Tp * Cin
     dU = Qt + 4 * P * Tp * Cout
     s = _stream()
-    if PROFILER is None:
+    kept = _wino_v_get(x, bool(relu_in), tile)          # the forward launch's transform of this very tensor (or of the batch it is a slice of)
+    v_rows = 0
+    if kept is not None:
+        V, v_rows = kept
+    elif PROFILER is None:
         call("sg_conv2d_bwd_weight_wino", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, 1 if relu_in else 0, tile, V, nbytes, s)
         return
-    with _hbm("wino_transform", x, dy):
+    with _hbm("wino_transform", x if kept is None else None, dy):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
-            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * (Cin + Cout)
-        call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), tile, s)
+            PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * ((Cin if kept is None else 0) + Cout)
+        if kept is None:
+            call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), tile, s)
         call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), dU + 4 * P * Cin * Cout, B, H, W, Cout, tile, s)
     with _timed("wgrad_wino", 2.0 * P * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
         if PROFILER is not None and PROFILER.wants("wgrad_wino"):
             PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * P * (T * (Cin + Cout) + Cin * Cout)
-        call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, tile, s)
+        call("sg_wino_wgrad_gemm", V, Qt, dU, B, H, W, Cin, Cout, tile, v_rows, s)
     with _hbm("wino_transform", dw, dw):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * Cin * Cout

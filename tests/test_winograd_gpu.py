@@ -211,3 +211,38 @@ def test_sample_results_do_not_depend_on_the_batch_in_deterministic_mode(dev, wi
     finally:
         ops.set_deterministic(False)
     assert torch.equal(a, b) and torch.equal(a[:3], c)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(6, 8, 40, 128, 256), (5, 4, 20, 256, 256)])
+def test_weight_grad_reuses_the_forward_transform(dev, wino_everywhere, B, H, W, Cin, Cout):
+    """Inside a step (ops.new_step() ... ops.end_step()) the forward launch keeps its transformed input and the weight gradient of the
+    same tensor -- or of a batch slice of it, as the per-target sweeps of a fused pass use -- reads it instead of transforming
+    relu(x) again: same dW / db as without the registry (float-atomic order only), and the registry is empty after the step."""
+    ops = wino_everywhere
+    g = torch.Generator(device=dev).manual_seed(B + Cin)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g)
+    sc = torch.rand(B, device=dev, generator=g) + 0.5
+
+    def grads(lo, hi):
+        dw, db = torch.zeros_like(w), torch.zeros(Cout, device=dev)
+        ops.conv2d_bwd_weight(x[lo:hi], dy[lo:hi].contiguous(), dw, relu_in=True, db=db, sample_scale=sc[lo:hi].contiguous())
+        return dw, db
+
+    ref = [grads(0, B), grads(2, B), grads(0, 2)]
+    ops.new_step()
+    try:
+        y = ops.conv2d_fwd(x, w, relu_in=True)
+        assert ops._WINO_V["map"], "the forward launch kept nothing"
+        kept = ops._wino_v_get(x[2:], True, ops._wino_tile(H, W))
+        assert kept is not None and kept[1] == -(-(B * (H // ops._wino_tile(H, W)) * (W // ops._wino_tile(H, W))) // 128) * 128
+        got = [grads(0, B), grads(2, B), grads(0, 2)]
+        assert ops._wino_v_get(x, False, ops._wino_tile(H, W)) is None            # (another operand ReLU: not the same transform)
+    finally:
+        ops.end_step()
+    assert not ops._WINO_V["map"] and not ops._WINO_V["on"]
+    for (dw, db), (rw, rb), name in zip(got, ref, ("whole batch", "samples 2..", "samples ..2")):
+        _close(dw, rw, 1e-5, "dW with the kept transform, " + name)
+        _close(db, rb, 1e-5, "db, " + name)
+    _close(y, ops.conv2d_fwd(x, w, relu_in=True), 1e-7, "forward result with V in its own tensor")

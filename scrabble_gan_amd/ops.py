@@ -125,14 +125,22 @@ def _stream() -> int:
 # modes (operand copies made on one stream are read on the other), and for launches of more than SIDE_MAX_BATCH samples: measured
 # on MI355X (profiles/r03_side_stream.txt), per-GPU batch 16: 52.98 -> 52.04 ms / step (+1.8 %); batch 128: 346.1 -> 349.8 ms
 # (-1 %: the grids fill many rounds of the chip, two resident kernels only compete for L2).  SG_SIDE_WGRAD=0 disables it.
-SIDE_WGRAD = _os.environ.get("SG_SIDE_WGRAD", "1") == "1"
+# Round 3, after the Winograd path: OFF by default.  The shard-size step shrank to ~32 ms of GPU work and the 13-37 stream waits a step
+# needs cost the host 0.3-1 ms EACH (hipStreamWaitEvent, box-dependent: profiles/r03_host_profile_bs16.txt, r03_streams_bs16.txt) -- on a
+# slow host the step became host-bound (43.8 ms with the side streams against 40.1 ms on one stream) for a gain of 1.8 % on a fast one.
+# The network stream below (a handful of joins per step, +3.4 %) stays on.  SG_SIDE_WGRAD=1 turns the side streams back on.
+SIDE_WGRAD = _os.environ.get("SG_SIDE_WGRAD", "0") == "1"
 SIDE_MAX_BATCH = int(_os.environ.get("SG_SIDE_MAX_BATCH", "96"))
 _SIDE = {}             # raw handle of the stream that is "main" for a sweep -> {"stream": its side stream, "dirty": bool}
 CAPTURING = False      # graph_step.GraphedStep sets this while a step is captured into a HIP graph (single stream)
 
 
+def _streams_ok() -> bool:
+    return PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32" and not CAPTURING
+
+
 def side_enabled() -> bool:
-    return SIDE_WGRAD and PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32" and not CAPTURING
+    return SIDE_WGRAD and _streams_ok()
 
 
 def _side_of_current():
@@ -197,7 +205,7 @@ _NET = {"stream": None}
 
 
 def net_stream_enabled(batch: int) -> bool:
-    return NET_STREAM and side_enabled() and batch <= SIDE_MAX_BATCH
+    return NET_STREAM and _streams_ok() and batch <= SIDE_MAX_BATCH
 
 
 class net_stream:

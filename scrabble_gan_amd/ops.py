@@ -124,7 +124,7 @@ def _stream() -> int:
 # kernel timing is active (HIP-event brackets would measure overlapped launches), in deterministic mode, and in bf16 / fp8
 # modes (operand copies made on one stream are read on the other), and for launches of more than SIDE_MAX_BATCH samples: measured
 # on MI355X (profiles/r03_side_stream.txt), per-GPU batch 16: 52.98 -> 52.04 ms / step (+1.8 %); batch 128: 346.1 -> 349.8 ms
-# (-1 %: the grids fill many rounds of the chip, two resident kernels only compete for L2).  SG_SIDE_WGRAD=0 disables it.
+# (-1 %: the grids fill many rounds of the chip, two resident kernels only compete for L2).
 # Round 3, after the Winograd path: OFF by default.  The shard-size step shrank to ~32 ms of GPU work and the 13-37 stream waits a step
 # needs cost the host 0.3-1 ms EACH (hipStreamWaitEvent, box-dependent: profiles/r03_host_profile_bs16.txt, r03_streams_bs16.txt) -- on a
 # slow host the step became host-bound (43.8 ms with the side streams against 40.1 ms on one stream) for a gain of 1.8 % on a fast one.

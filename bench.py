@@ -457,6 +457,13 @@ def main():
         line["backend"] = (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)"
         line["collectives_per_step"] = res["calls_timed"] / max(1, args.steps) if world > 1 else 0
         line.update(roofline_of(res, args.conv_dtype, world))
+        if res["ks"] is not None and res["timed_steps"]:
+            # what the matrix cores executed in one step (every MFMA conv family, Winograd-domain products counted as such) over the
+            # step time: the whole-step fraction of the MFMA peak, next to the dominant kernel's own fraction in `roofline`
+            fl = sum(v.get("flops", 0.0) for k, v in res["ks"].items() if not k.endswith("_thin")) / res["timed_steps"]      # (rank 0's own launches)
+            pk = PEAK_TF["f32"] if args.conv_dtype == "f32" else None
+            line["step_mfma_executed"] = {"tflop_per_step_per_gpu": fl / 1e12, "tflops_per_gpu": fl / (ms * 1e-3) / 1e12,
+                                          "frac_of_mfma_peak": (fl / (ms * 1e-3) / 1e12 / pk) if pk else None}
         if extra:
             line["configs"] = extra
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -410,15 +410,18 @@ def main():
     # steps, on freshly built models, each with its own warm-up; single GPU only (the scaling runs time c2 alone)
     extra = {}
     if plain_invocation and world == 1 and not args.no_extra_configs and not args.no_kernel_timing:
-        for tag, cd, eb, bal in (("c3", "bf16", 256, False), ("c5", "fp8", 512, True)):
+        for tag, cd, eb, bal in (("c3", "bf16", 256, False), ("c4", "f32", 256, False), ("c5", "fp8", 512, True)):
             try:
-                r = measure(cd, eb, 10, bal, max(3, min(args.steps, 10)), 2, 1, reducer, dev, world, hbm_families=True)
+                bk = tag == "c4"            # c4: one (L_r, L_f) pair per step from a shared stream, L in [4, 23] (data_utils.py:62-84,386-392)
+                r = measure(cd, eb, 10, bal, max(3, min(args.steps, 10)), 2, 1, reducer, dev, world, hbm_families=True, bucketed=bk)
                 r["hbm_steps"] = 1
                 v = eb * r["steps"] / r["elapsed"]
-                ent = {"workload": WORKLOADS[cd] % (eb, 10) + (", gradient balancing on" if bal else ""), "value": v, "unit": "images/s",
+                ent = {"workload": ("c4: synthetic random_words 32x(16 L), (L_r, L_f) ~ U{4..23}^2 per step, global bs %d, fp32 MFMA convs "
+                                    "(F(4x4,3x3) / F(2x2,3x3) Winograd-domain products); 1 of the 8 GPUs c4 names, whole batch" % eb) if bk else
+                                   WORKLOADS[cd] % (eb, 10) + (", gradient balancing on" if bal else ""), "value": v, "unit": "images/s",
                        "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "steps": r["steps"], "warmup": 2, "dtype": DTYPE_NAME[cd],
                        "global_batch": eb, "host_enqueue_ms_per_step": r["host_enqueue"] / r["steps"] * 1e3,
-                       "step_algorithmic_tflops": FLOP_PER_IMAGE * v / 1e12}
+                       "step_algorithmic_tflops": None if bk else FLOP_PER_IMAGE * v / 1e12}
                 ent.update(roofline_of(r, cd, world))
                 extra[tag] = ent
             except Exception as e:  # noqa: BLE001  (the headline line must still be printed)

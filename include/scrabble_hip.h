@@ -352,6 +352,12 @@ int sg_rccl_comm_destroy(void* comm);
  * CU-quantum tail split.  Returns the previous setting. */
 int sg_set_deterministic(int on);
 
+/* ---- self-test of the status convention -------------------------------------------------------------------------------
+ * Every entry point returns SG_ERR_LAUNCH if ANY of the launches it queued failed, not only the last one.
+ * sg_selftest_launch_status queues: a valid launch, a launch with an impossible block size (2048 threads), a valid
+ * launch -- and returns what an entry point would: SG_ERR_LAUNCH.  scratch: >= 256 floats (overwritten). */
+int sg_selftest_launch_status(float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

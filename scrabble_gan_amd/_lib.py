@@ -72,6 +72,9 @@ _ERR = {-1: "SG_ERR_ARG (bad argument / unsupported shape)", -2: "SG_ERR_LAUNCH 
 
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name)
+    if len(args) != len(fn.argtypes):           # (cdecl: ctypes itself lets surplus arguments through)
+        raise TypeError("%s takes %d arguments (%s), %d given" % (name, len(fn.argtypes), ", ".join(_decls[name][2]), len(args)))
+    rc = fn(*args)
     if rc != 0:
         raise ScrabbleHipError("%s failed: %s" % (name, _ERR.get(rc, rc)))

@@ -402,3 +402,14 @@ extern "C" int sg_bias_add(float* y, const float* bias, long M, int C, void* str
   LAUNCH(k_bias_add, M * (C / 4), stream, y, bias, M * (C / 4), C / 4);
   return sg_launch_status();
 }
+
+// ---- self-test of SG_KERNEL / sg_launch_status (sg_common.h): a failed launch in the MIDDLE of a sequence must surface
+__global__ void k_selftest_fill(float* p, float v) { p[threadIdx.x & 255] = v; }
+extern "C" int sg_selftest_launch_status(float* scratch, void* stream) {
+  if (!scratch) return SG_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SG_KERNEL(k_selftest_fill, dim3(1), dim3(256), 0, s, scratch, 1.f);
+  SG_KERNEL(k_selftest_fill, dim3(1), dim3(2048), 0, s, scratch, 2.f);      // more threads than a workgroup can hold: the launch is refused
+  SG_KERNEL(k_selftest_fill, dim3(1), dim3(256), 0, s, scratch, 3.f);
+  return sg_launch_status();
+}

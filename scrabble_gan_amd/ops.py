@@ -754,11 +754,25 @@ def _wino_tile(H: int, W: int) -> int:
     return 4 if (WINO_TILE == 4 and H % 4 == 0 and W % 4 == 0) else 2
 
 
-def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
+# Few-tile launches: every one of the (tile + 2)^2 frequency planes is padded to 128 rows, the direct form pads its B H W pixels ONCE.  At
+# T = 18 tiles (the recognizer's 8 x 12 map at B = 3) F(4x4) multiplies 36 x 128 rows where the direct kernel multiplies 9 x 384: more
+# products, not fewer.  The Winograd path is taken only where its padded row count is below WINO_ROW_GAIN x the direct form's (its
+# products run at ~0.75 of the direct loop's rate per row: short reductions); 0 switches the criterion off (the kernels' own tests).
+WINO_ROW_GAIN = float(_os.environ.get("SG_WINO_ROW_GAIN", "0.75"))
+
+
+def _wino_rows_ok(B, H: int, W: int, tile: int) -> bool:
+    if B is None or WINO_ROW_GAIN <= 0:
+        return True
+    T = B * (H // tile) * (W // tile)
+    return (tile + 2) ** 2 * (-(-T // 128) * 128) <= WINO_ROW_GAIN * 9 * (-(-(B * H * W) // 128) * 128)
+
+
+def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int, B=None) -> bool:
     if not (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0 and K % 32 == 0 and N % 128 == 0):
         return False
     t = _wino_tile(H, W)
-    return min(K, N) >= WINO_MIN_C[t] and K * N >= WINO_MIN_KN[t]
+    return min(K, N) >= WINO_MIN_C[t] and K * N >= WINO_MIN_KN[t] and _wino_rows_ok(B, H, W, t)
 
 
 def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -896,7 +910,7 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
         if GHOST_NAN:
             out.fill_(float("nan"))
         _TWINS[(out.untyped_storage().data_ptr(), "ghost")] = (out,)
-    if _wino_ok(Cin, Cout, kh, kw, same, H, W) and not tanh_out:
+    if _wino_ok(Cin, Cout, kh, kw, same, H, W, B) and not tanh_out:
         _wino_conv(x, w, out, bias, bias2, None, Cin, Cout, relu_in, _flags(False, accum, relu_out),
                    ("wino_fwd", B, Ho, Wo, Cin, Cout, kh))
         return out
@@ -946,7 +960,7 @@ def conv2d_bwd_data(dy, w, in_hw: Tuple[int, int], mask=None, same=True, out=Non
     if out is None:
         out = empty(B, H, W, Cin, like=dy)
     use8 = _fp8_ok(Cout, Cin, kh, kw, same)
-    if _wino_ok(Cout, Cin, kh, kw, same, H, W) and tuple(dy.shape[1:3]) == (H, W):
+    if _wino_ok(Cout, Cin, kh, kw, same, H, W, dy.shape[0]) and tuple(dy.shape[1:3]) == (H, W):
         _wino_conv(dy, w, out, None, None, mask, Cout, Cin, False, _flags(accum=accum),
                    ("wino_dgrad", B, H, W, Cin, Cout, kh))
         return out

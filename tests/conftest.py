@@ -12,6 +12,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Bottom-up order of the suite: the kernels' own parity tests run before anything composed of them, so that under `-x` a red
+# network-level test can never hide the verdict of the layer beneath it (round 3: one recognizer gradient stopped the run
+# before any per-op / Winograd test was reached).  Files not listed keep their place after the listed ones.
+_ORDER = ["test_oracle_known_answers", "test_winograd_cpu", "test_host_cpu", "test_dp_gloo", "test_golden",
+          "test_ops_gpu", "test_winograd_gpu", "test_bf16_gpu", "test_fp8_gpu", "test_fullsize_nonconv_gpu", "test_fullsize_gpu",
+          "test_nets_gpu", "test_configs_gpu", "test_dp_gpu", "test_train_loop_gpu"]
+_LATE_IN_FILE = ("test_train_step", "test_shared_sweeps", "test_widest_bucket")      # whole-step tests of test_nets_gpu.py: after its networks
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        rank = _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+        late = 1 if item.name.startswith(_LATE_IN_FILE) else 0
+        return (rank, late)
+    items.sort(key=key)         # stable: definition order inside a file is kept
+
+
+@pytest.fixture(autouse=True)
+def _margin_context(request):
+    from tests import margins
+    margins.CURRENT[0] = request.node.nodeid
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import margins
+    margins.dump()
+
+
 @pytest.fixture(scope="session")
 def dev():
     import torch

@@ -64,7 +64,7 @@ def test_c4_bucketed_step_against_oracle(NA, dev):
     check_step_against_calibrated_oracle(NA, dev, pb, "hinge", False, "c4_Lr3_Lf2", bucket_size=23)
 
 
-def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None):
+def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None, z_scale=None, spread_styles=False):
     """One train_step at global batch B, L_r = L_f = 10, in fp32 mode and in `mode`, on identical weights, inputs and NonLocalBlock
     kernels -> {mode: (16 scalars, {net: flat gradient}, fake images)}."""
     from scrabble_gan_amd import data_utils as DU, net_loss, nn, ops, optimizers
@@ -72,6 +72,8 @@ def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None):
     images, labels, my_imgs = DU.synthetic_batch(B, L, seed=3)
     words = DU.synthetic_random_words(10, 300, seed=3)
     fake = np.array(words[L - 1][:B], np.int32)
+    if spread_styles:          # style images with different mean levels (tests/step_fixture.py): the fakes of an untrained G then differ
+        my_imgs = np.clip(0.3 * my_imgs + np.linspace(-1, 1, B, dtype=np.float32).reshape(B, 1, 1, 1), -1, 1).astype(np.float32)
     res = {}
     try:
         for md in ("f32", mode):
@@ -86,6 +88,8 @@ def _step_in_two_modes(NA, dev, B, mode, balance, dense_scale=None):
                 for k in m.store.names:
                     if k.endswith(".sigma"):
                         m.store.p[k].fill_(0.25)
+            if z_scale is not None:
+                G.store.p["zdense.w"].mul_(z_scale)
             if dense_scale is not None:                   # logits O(1): std(g_loss) is then not a difference of nearly equal numbers
                 for m in (D, S):
                     m.store.p["dense.w"].mul_(dense_scale)

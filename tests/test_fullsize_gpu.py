@@ -11,6 +11,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
+
 SHAPES = [  # H, W, Cin, Cout, k
     (32, 160, 64, 64, 3), (16, 80, 64, 512, 3), (16, 80, 512, 512, 3), (8, 40, 512, 1024, 3), (8, 40, 1024, 1024, 3),
     (4, 20, 1024, 1024, 3), (8, 40, 512, 1024, 1), (4, 40, 512, 512, 3),
@@ -112,6 +114,7 @@ def _close(got, ref, tol, name):
     got, ref = got.double().cpu(), ref.double().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item() + 1e-30
+    margins.record(name, err / scale, tol)
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
 
 

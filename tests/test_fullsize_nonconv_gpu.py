@@ -16,6 +16,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
+
 from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
 
 
@@ -24,6 +26,7 @@ def _close(got, ref, tol, name):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     assert torch.isfinite(got).all(), name
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item() + 1e-30
+    margins.record(name, err / scale, tol)
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
 
 
@@ -297,17 +300,22 @@ def test_recognizer_fused_pass_vs_oracle_at_launch_geometry(dev):
     (loss_f, loss_r), ctx, bounds = R.forward_multi(xs, labs, T, L, training=True)
     up = torch.rand(B, device=dev, generator=g) + 0.5
     dx = R.backward(R.slice_ctx(ctx, 0, B), up, want_dx=True, want_dw=False)
+    from tests import step_fixture as F
+    from tests.test_nets_gpu import _with_hip_decisions
     for c, (x, lab, loss) in enumerate(zip(xs, labs, (loss_f, loss_r))):
         xe = _edge(x).requires_grad_(True)
-        ref = O.recognizer(xe, _edge_i(lab), T, L, P, bn_training=False)
+        lo = bounds[c][0]
+        # frozen BatchNorm: samples are independent, so the four edge samples can be checked on their own -- under the ReLU /
+        # max-pool decisions the HIP pass took for THEM (1.3 M activations per sample: a handful of near-ties fall the other way
+        # in fp32 and re-route single pixels of the image gradient by up to 1.2e-2 of max|ref|; with the decisions imposed the
+        # fixed 1e-3 gradient bound of tests/test_nets_gpu.py::test_recognizer holds)
+        relu, pool = F.recognizer_decisions(R.slice_ctx(ctx, lo, lo + B))
+        ref = _with_hip_decisions(lambda: O.recognizer(xe, _edge_i(lab), T, L, P, bn_training=False), ([_edge(t) for t in relu], [_edge(t) for t in pool]),
+                                  "frozen recognizer, call %d" % c)
         _close(_edge(loss.reshape(-1, 1)), ref, 1e-4, "CTC cost of call %d (first / last 2 samples)" % c)
         if c == 0:
             (ref[:, 0] * _edge(up)).sum().backward()
-            # dx crosses 4 max-pools and 7 ReLU masks over 1.3 M activations per sample: a near-tie resolved differently in
-            # fp32 re-routes single pixels (measured: max 1.2e-2 of max|ref| at a handful of pixels) -- the whole gradient is
-            # held in the L2 norm at 1e-2 (measured 3.5e-3), single pixels at 3e-2 (tests/test_nets_gpu.py::test_recognizer: 5e-3 at 32 x 48)
-            _close_l2(_edge(dx), xe.grad, 1e-2, "image gradient through the frozen recognizer (L2)")
-            _close(_edge(dx), xe.grad, 3e-2, "image gradient through the frozen recognizer")
+            _close(_edge(dx), xe.grad, 1e-3, "image gradient through the frozen recognizer")
 
 
 def _edge_i(t, n=2):
@@ -319,9 +327,11 @@ def test_generator_vs_oracle_at_the_shard_geometry(dev):
     data-parallel shard (B = 16 words of 10 characters, 160-wide style images): style encoder, z, filter bank, the three
     ResNetBlockUp with ConditionalBatchNorm over the batch's own statistics (10 240 ... 81 920 pixels), the NonLocalBlock at
     5120 x 1280, final BN + conv + tanh -- image 1e-4; every gradient tensor with the criterion of tests/test_nets_gpu.py::
-    test_generator (max-norm 1e-2 of max|ref|, or L2 2.5e-3 with <= 1 % outliers where a ReLU decision flipped); moving statistics."""
+    test_generator (fixed max-norm bound against the fp64 oracle under the HIP pass's own ReLU / max-pool decisions, which must
+    equal the oracle's except at near-ties); moving statistics."""
     from scrabble_gan_amd import net_architecture as NA
-    from tests.test_nets_gpu import close, close_grad, leaves, net_atol
+    from tests import step_fixture as F
+    from tests.test_nets_gpu import GEN_GRAD_TOL, _with_hip_decisions, close, leaves, net_atol
     NA.configure(device=dev, seed=3)
     gen = torch.Generator().manual_seed(7)
     G = NA.make_generator(128, (32, 160, 1), (32, 8192), None, "B3", 52, vis_model=False)
@@ -332,17 +342,17 @@ def test_generator_vs_oracle_at_the_shard_geometry(dev):
     nls_o, nlu_o = O.init_nonlocal(64, gen), O.init_nonlocal(64, gen)
     nls_g, nlu_g = ({k: v.float().to(dev).contiguous() for k, v in d.items()} for d in (nls_o, nlu_o))
     dimg = torch.randn(B, 32, 16 * L, 1, generator=gen, dtype=torch.float64)
-    lv = leaves(P)
-    stats = {}
-    ref = O.generator(style, y, P, nls_o, nlu_o, bn_stats=stats)
-    (ref * dimg).sum().backward()
     img, ctx = G.forward(style.float().to(dev), y.int().to(dev), nls_g, nlu_g, training=True)
-    close(img, ref, 1e-4, "image")
     G.store.zero_grad()
     G.backward(ctx, dimg.float().to(dev))
+    lv = leaves(P)
+    stats = {}
+    ref = _with_hip_decisions(lambda: O.generator(style, y, P, nls_o, nlu_o, bn_stats=stats), F.generator_decisions(ctx), "generator at the shard geometry")
+    (ref * dimg).sum().backward()
+    close(img, ref, 1e-4, "image")
     at = net_atol([v.grad for v in lv.values()])
     for k, v in lv.items():
-        close_grad(G.store.g[k], v.grad, 1e-2, "grad " + k, at)
+        close(G.store.g[k], v.grad, GEN_GRAD_TOL, "grad " + k, at)
     for pre in ("B1.cbn1", "B3.cbn2", "bn"):
         st = stats[pre]
         n = st["count"]

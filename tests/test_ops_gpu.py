@@ -9,6 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
+
 from oracle import scrabble_oracle as O  # noqa: E402  (checker only)
 
 
@@ -19,6 +21,7 @@ def close(got, ref, tol=2e-5, name=""):
     assert torch.isfinite(got).all(), name
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item() + 1e-12
+    margins.record(name, err / scale, tol)
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
 
 
@@ -394,3 +397,19 @@ def test_adam_rmsprop_spectral(dev, gen):
     w, u = rnd(gen, 3, 3, 16, 40), rnd(gen, 1, 40)
     close(ops.spectral_norm(g32(w, dev), g32(u.reshape(-1), dev)), O.spectral_norm(w, u), tol=2e-5, name="spectral_norm")
     close(ops.spectral_norm(g32(w, dev), g32(u.reshape(-1), dev), 3), O.spectral_norm(w, u, 3), tol=2e-5, name="spectral_norm3")
+
+
+def test_launch_status_keeps_an_earlier_failure(dev):
+    """The C-ABI convention 'returns 0 or a negative code' must hold for entry points that queue several launches: a launch
+    refused in the MIDDLE of the sequence (2048 threads per workgroup) is reported although the launch after it succeeds
+    (sg_common.h: SG_KERNEL folds every launch's status into the flag sg_launch_status() returns), and the flag is reset."""
+    from scrabble_gan_amd import _lib, ops
+    scratch = torch.zeros(256, device=dev)
+    rc = _lib.lib().sg_selftest_launch_status(scratch.data_ptr(), ops._stream())
+    assert rc == -2, rc
+    torch.cuda.synchronize()
+    assert scratch[0].item() == 3.0                     # the launches around the refused one ran
+    out = ops.add(torch.ones(8, device=dev), torch.ones(8, device=dev))     # the next entry point starts from a clean slate
+    assert out.sum().item() == 16.0
+    with pytest.raises(TypeError):                      # arity is checked on the host before anything reaches the GPU
+        _lib.call("sg_add", scratch.data_ptr(), scratch.data_ptr(), scratch.data_ptr(), 8)

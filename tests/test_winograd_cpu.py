@@ -94,6 +94,13 @@ def test_routing_of_the_step_s_convolutions():
     for K, N, kh, same, H, W in [(64, 64, 3, True, 32, 160), (512, 64, 3, True, 16, 80), (512, 1024, 1, True, 8, 40), (512, 512, 3, False, 16, 80),
                                  (512, 512, 3, True, 5, 80), (1, 64, 3, True, 32, 160), (512, 512, 2, True, 2, 40)]:
         assert not ops._wino_ok(K, N, kh, kh, same, H, W), (K, N, kh, same, H, W)
+    # few-tile launches (every frequency plane is padded to 128 rows): the recognizer's 8 x 12 map at B = 3 has 18 tiles -- 36 x 128 rows
+    # against the direct form's 9 x 384 -- and stays direct; every layer of the headline batch and of its 8-way shard goes through
+    assert not ops._wino_ok(128, 256, 3, 3, True, 8, 12, 3) and not ops._wino_ok(512, 512, 3, 3, True, 4, 12, 3)
+    for B in (16, 128, 384):
+        for K, N, H, W in yes:
+            assert ops._wino_ok(K, N, 3, 3, True, H, W, B), (B, K, N, H, W)
+    assert ops._wino_ok(1024, 1024, 3, 3, True, 4, 20, 16) and not ops._wino_ok(1024, 1024, 3, 3, True, 4, 16, 4)    # T = 80 / 16 tiles
     assert ops._wino_wgrad_ok(64, 64, 3, 3, True, 32, 160) and ops._wino_wgrad_ok(64, 512, 3, 3, True, 16, 80)
     assert not ops._wino_wgrad_ok(1, 64, 3, 3, True, 32, 160) and not ops._wino_wgrad_ok(512, 512, 1, 1, True, 8, 40)
     old = ops.CONV_DTYPE

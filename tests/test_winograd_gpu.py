@@ -17,16 +17,18 @@ from oracle import scrabble_oracle as O  # checker only
 
 pytestmark = pytest.mark.gpu
 
+from tests import margins  # noqa: E402
+
 
 @pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
 def wino_everywhere(request):
     """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path; F4x4: F(4x4, 3x3) wherever H and W
     are multiples of 4 (the other shapes of the lists then run F(2x2, 3x3) again)."""
     from scrabble_gan_amd import ops
-    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES)
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES = {2: 32, 4: 32}, {2: 0, 4: 0}, True, request.param, 0
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES, ops.WINO_ROW_GAIN)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES, ops.WINO_ROW_GAIN = {2: 32, 4: 32}, {2: 0, 4: 0}, True, request.param, 0, 0.0
     yield ops
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES = old
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES, ops.WINO_ROW_GAIN = old
 
 
 @pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
@@ -43,6 +45,7 @@ def _close(got, ref, tol, name):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     err, scale = (got - ref).abs().max().item(), ref.abs().max().item() + 1e-30
     print("%s: rel err %.3e" % (name, err / scale))
+    margins.record(name, err / scale, tol)
     assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e > %.1e)" % (name, err, scale, err / scale, tol)
 
 

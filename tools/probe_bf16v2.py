@@ -56,11 +56,11 @@ def main():
 
         def f_v2():
             call("sg_conv2d_fwd_bf16v2", x16.data_ptr(), wp_f.data_ptr(), bias.data_ptr(), None, y.data_ptr(), y16.data_ptr(), B, H, W,
-                 Cin, Cout, k, k, 1, ops.RELU_IN, st())
+                 Cin, Cout, k, k, 1, ops.RELU_IN, None, st())
 
         def d_v2():
             call("sg_conv2d_bwd_data_bf16v2", dy16.data_ptr(), wp_b.data_ptr(), x.data_ptr(), None, dx.data_ptr(), None, B, H, W, Cin, Cout, k, k,
-                 1, 0, st())
+                 1, 0, None, None, st())
         line = "%3dx%3d %4d->%4d k%d B%d:" % (H, W, Cin, Cout, k, B)
         if Cout % 64 == 0:
             t = timeit(f_v2)
@@ -75,7 +75,7 @@ def main():
         dw = torch.zeros_like(w)
 
         def w_v2():
-            call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, k, k, 1, ops.RELU_IN, st())
+            call("sg_conv2d_bwd_weight_bf16v2", x16.data_ptr(), dy16.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, k, k, 1, ops.RELU_IN, None, st())
         wg2 = (Cin % 64 == 0 and Cout % 256 == 0) or (Cin == 64 and Cout == 64)
         if wg2:
             t = timeit(w_v2)

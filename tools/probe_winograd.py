@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO4_WGRAD_MIN_TILES = {2: 32, 4: 32}, {2: 0, 4: 0}, 0
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO4_WGRAD_MIN_TILES, ops.WINO_ROW_GAIN = {2: 32, 4: 32}, {2: 0, 4: 0}, 0, 0.0
     print("%-18s | %21s | %21s | %21s   (ms direct / Winograd, ratio)" % ("layer", "fwd", "dgrad", "wgrad"))
     for name, B, H, W, Ci, Co in SHAPES:
         x = torch.randn(B, H, W, Ci, device=dev)

@@ -150,6 +150,9 @@ def committed_traffic(kernel, conv_dtype, per_gpu_batch):
     return tj["traffic_bytes_per_launch"], "%s @ %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.py)" % (rel, stamp)
 
 
+TIMING_IN_REGION = False
+
+
 def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev, world, bucketed=False, sync_every_step=False,
             kernel_timing=True, shape_table=None, hbm_families=True, graph=False):
     """Build the four networks, run `warmup` + `steps` train_steps of one configuration with the inputs resident in HBM, and
@@ -211,8 +214,12 @@ def measure(conv_dtype, B, L, balance, steps, warmup, timing_steps, reducer, dev
     # Kernel timing (HIP events around every MFMA conv launch, on the launch stream) runs inside the timed region at
     # N = 1.  At N > 1 the per-GPU batch is small enough for the event records to cost a few percent, so there the
     # timed region runs bare and the roofline figures come from --timing-steps extra steps right after it.
+    # Round 4: the timed region runs BARE at every N -- exactly the path scrabble_gan_amd.data_utils.train runs (two HIP streams: S's
+    # passes beside D's and R's; one C-ABI call per Winograd-domain convolution) -- and the per-kernel HIP-event timing happens in
+    # --timing-steps extra steps right after it, on one stream (a kernel's duration only measures the kernel while it has the GPU
+    # to itself).  --timing-in-region restores the round-3 behaviour (events inside the timed region, single stream).
     timer = ops.KernelTimer(only=("igemm", "wgrad")) if kernel_timing else None      # the MFMA conv kernels (+ their thin variants)
-    timing_in_region = timer is not None and world == 1
+    timing_in_region = timer is not None and world == 1 and TIMING_IN_REGION
     ops.PROFILER = timer if timing_in_region else None
     fence()
     calls_before = getattr(reducer, "calls", 0)          # collectives of the warm-up steps
@@ -354,6 +361,7 @@ def main():
     ap.add_argument("--L", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-in-region", action="store_true", help="HIP-event kernel timing inside the timed region (single stream, N = 1) instead of in extra steps after it")
     ap.add_argument("--timing-steps", type=int, default=2, help="extra steps after the timed region for the per-kernel HIP-event timing of the memory-bound families (and, at N > 1, of the conv kernels)")
     ap.add_argument("--conv-dtype", default=None, choices=["f32", "bf16", "fp8"],
                     help="matrix-core operand type of the convolutions: f32 = the headline config c2 (default); bf16 = config c3 (run it with --batch 256); "
@@ -371,6 +379,8 @@ def main():
                          "roofline object is omitted) -- for the small-batch bf16 / fp8 steps whose host time is within 2x of the GPU time")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + one all-reduce only, no GPU work (launcher rehearsal on CPU)")
     args = ap.parse_args()
+    global TIMING_IN_REGION
+    TIMING_IN_REGION = bool(args.timing_in_region)
     plain_invocation = args.conv_dtype is None and args.batch is None and not args.bucketed and not args.balance and args.L == 10 and not args.graph
     if args.conv_dtype is None:
         args.conv_dtype = "f32"

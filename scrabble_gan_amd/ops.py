@@ -135,8 +135,11 @@ _SIDE = {}             # raw handle of the stream that is "main" for a sweep -> 
 CAPTURING = False      # graph_step.GraphedStep sets this while a step is captured into a HIP graph (single stream)
 
 
+STREAMS_LOWP = _os.environ.get("SG_STREAMS_LOWP", "0") == "1"      # (experiment, round 4: the network stream in bf16 / fp8 mode too)
+
+
 def _streams_ok() -> bool:
-    return PROFILER is None and not DETERMINISTIC and CONV_DTYPE == "f32" and not CAPTURING
+    return PROFILER is None and not DETERMINISTIC and (CONV_DTYPE == "f32" or STREAMS_LOWP) and not CAPTURING
 
 
 def side_enabled() -> bool:
@@ -204,8 +207,15 @@ NET_STREAM = _os.environ.get("SG_NET_STREAM", "1") == "1"
 _NET = {"stream": None}
 
 
+# Round 4: at EVERY batch size.  At the headline batch the launches fill the chip many times over, but a network pass alternates
+# matrix-bound launches (the grouped Winograd products) with HBM-bound ones (the transform sweeps at 7 TB/s, pools, BN); with S on its
+# own stream the HBM-bound launches of one network run under the matrix-bound ones of the other: 148.5 -> 140.4 ms / step at bs 128 on
+# the same box (profiles/r04_streams_bs128.txt; the weight-grad side streams on top of it: 143.5 ms -- they stay off).
+NET_MAX_BATCH = int(_os.environ.get("SG_NET_MAX_BATCH", str(1 << 30)))
+
+
 def net_stream_enabled(batch: int) -> bool:
-    return NET_STREAM and _streams_ok() and batch <= SIDE_MAX_BATCH
+    return NET_STREAM and _streams_ok() and batch <= NET_MAX_BATCH
 
 
 class net_stream:
@@ -243,8 +253,20 @@ class net_stream:
                 t.record_stream(self.main)
 
 
+_GHOSTS = set()        # storage pointers of the never-written fp32 handles behind operand-only results (bf16 / fp8 modes), this step
+
+
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    """Raw device pointer of an fp32 tensor for the C-ABI.  A never-written handle of an operand-only result (conv2d_fwd(want16=
+    'only'), avgpool2_bwd_operands) has no fp32 contents: every consumer must read its bf16 / fp8 copy, so handing its fp32
+    pointer to a kernel is a routing bug (e.g. the mode flags changed between forward and backward) and fails here, loudly,
+    instead of computing on uninitialised memory."""
+    if t is None:
+        return None
+    if _GHOSTS and t.untyped_storage().data_ptr() in _GHOSTS:
+        raise RuntimeError("fp32 contents of an operand-only result requested (shape %s): its consumers must read the bf16 / fp8 copy; "
+                           "conv dtype / deterministic mode changed between the forward and the backward pass?" % (tuple(t.shape),))
+    return t.data_ptr()
 
 
 def _chk(*ts):
@@ -283,6 +305,7 @@ def set_conv_dtype(dtype: str) -> None:
     CONV_DTYPE = dtype
     _PACK_CACHE.clear()
     _TWINS.clear()
+    _GHOSTS.clear()
 
 
 _FP8_BLOCK = [0]
@@ -439,6 +462,7 @@ def avgpool2_bwd_operands(dout: torch.Tensor, wscale=None, want_dw: bool = True)
     if GHOST_NAN:
         ghost.fill_(float("nan"))
     gp, n = ghost.untyped_storage().data_ptr(), ghost.numel()
+    _GHOSTS.add(gp)
     sptr = 0 if wscale is None else wscale.data_ptr()
     colsum = _grad_colsum(dout, wscale) if want_dw else None
     if use16:
@@ -591,6 +615,7 @@ def _amax_get(t: torch.Tensor, scale=None, need_scaled: bool = False):
 
 def new_step() -> None:
     _TWINS.clear()
+    _GHOSTS.clear()
     _AMAX_POOL["buf"] = None
     _WINO_V["map"].clear()
     _WINO_V["on"] = WINO_KEEP_V
@@ -607,6 +632,7 @@ def _touch(t) -> None:
         _WINO_V["map"].pop(t.untyped_storage().data_ptr(), None)
     if t is not None and _TWINS:
         k = t.untyped_storage().data_ptr()
+        _GHOSTS.discard(k)
         _TWINS.pop(k, None)
         for kk in [kk for kk in _TWINS if isinstance(kk, tuple) and kk[0] == k]:
             del _TWINS[kk]
@@ -627,6 +653,7 @@ def _twin_put(t: torch.Tensor, t16: torch.Tensor) -> None:
         return
     if len(_TWINS) > 512:
         _TWINS.clear()
+        _GHOSTS.clear()
     _TWINS[t.untyped_storage().data_ptr()] = (t, t16.view(-1))
 
 
@@ -762,7 +789,7 @@ WINO_ROW_GAIN = float(_os.environ.get("SG_WINO_ROW_GAIN", "0.75"))
 
 
 def _wino_rows_ok(B, H: int, W: int, tile: int) -> bool:
-    if B is None or WINO_ROW_GAIN <= 0:
+    if B is None or WINO_ROW_GAIN <= 0 or DETERMINISTIC:       # (deterministic mode: a sample's result must not depend on the batch it rides in)
         return True
     T = B * (H // tile) * (W // tile)
     return (tile + 2) ** 2 * (-(-T // 128) * 128) <= WINO_ROW_GAIN * 9 * (-(-(B * H * W) // 128) * 128)
@@ -910,6 +937,7 @@ def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=F
         if GHOST_NAN:
             out.fill_(float("nan"))
         _TWINS[(out.untyped_storage().data_ptr(), "ghost")] = (out,)
+        _GHOSTS.add(out.untyped_storage().data_ptr())
     if _wino_ok(Cin, Cout, kh, kw, same, H, W, B) and not tanh_out:
         _wino_conv(x, w, out, bias, bias2, None, Cin, Cout, relu_in, _flags(False, accum, relu_out),
                    ("wino_fwd", B, Ho, Wo, Cin, Cout, kh))

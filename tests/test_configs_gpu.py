@@ -125,32 +125,53 @@ def test_c3_bf16_step_at_bs256_tracks_fp32(NA, dev):
 
 
 def test_c5_fp8_step_at_the_bs64_shard_tracks_fp32(NA, dev):
-    """Config c5 at its 8-way shard size (global batch 512 -> 64 per GPU), L_r = L_f = 10, gradient balancing ON: fp8 forward /
-    data-grad (e4m3) and weight-grad (e4m3 x e5m2) launches of the >= 256-channel convolutions of G / D / S at their real
-    launch geometry (fused passes of 128 / 192 samples: 1 280 ... 7 680 output tiles, fp8 weight-grads over 61 440 ...
-    245 760 pixels), bf16 elsewhere, against the same step in fp32 mode.  D / S final Dense x 70 (logits O(1): balancing
-    divides by std(g_loss)).  e4m3 keeps 3 mantissa bits, e5m2 2: scalars within 0.2 * max(1, |fp32|), gradient cosines
-    D / S / R > 0.9, G > 0.75 (measured 0.80-0.85 run to run: G's gradient passes through the balancing ratio 1 / std(g_loss) of 64
-    samples, where e4m3 / e5m2 noise is largest; D / S / R measure 0.995+; values are written to
-    gpurun_out/c5_bs64_tracking.txt), fake images within 0.15."""
+    """Config c5 at its 8-way shard size (global batch 512 -> 64 per GPU), L_r = L_f = 10: fp8 forward / data-grad (e4m3) and
+    weight-grad (e4m3 x e5m2) launches of the >= 256-channel convolutions of G / D / S at their real launch geometry (fused passes
+    of 128 / 192 samples), bf16 elsewhere, against the same step in fp32 mode.  D / S final Dense x 70 (logits O(1)).
+
+    The problem is CONDITIONED like tests/step_fixture.py (style images with different mean levels, z x 30): the 64 fakes of an
+    untrained G then differ (per-pixel spread 0.28 against 2e-4 on the round-3 problem, where the fakes were one image to fp8's
+    resolution and std(g_loss) -- a difference of nearly equal logits -- came out 18 % low in fp8: that scalar multiplies the
+    recognizer part of G's gradient one-to-one through the balancing ratio and WAS the 0.87 norm ratio / 0.80-0.85 cosine of round 3;
+    profiles/r04_diag_c5.txt.  The fp8 launches themselves are unbiased: gain 0.9985 forward / data-grad, 0.996 weight-grad per
+    launch, profiles/r04_diag_fp8_bias.txt; no underflow of the gradient operands, profiles/r04_diag_c5_quant.txt).
+
+    Two steps: (1) gradient balancing OFF -- no forward-side scalar in the gradient: |g(fp8)| / |g(fp32)| within +-3 % and cosine >
+    0.95 for every network (measured G 0.983 / 0.980, D 0.986 / 0.997, S 1.000 / 0.994, R 1.000 / 1.000);  (2) balancing ON (c5
+    itself): cosines D / S > 0.98 (measured 0.997 / 0.993), R > 0.999, G > 0.9 (measured 0.969; 0.75 was the bar of round 3), and G's norm ratio within 5 % of the interval between 1 and the
+    ratio of the two runs' balancing factors std(g_loss) / std(r_fake) (G's gradient = g_loss part + factor x recognizer part).
+    Scalars within 0.2 * max(1, |fp32|), fake images within 0.2 (z x 30 amplifies G's own fp8 rounding: measured 0.156).
+    Values are written to gpurun_out/c5_bs64_tracking.txt."""
     import os
-    res = _step_in_two_modes(NA, dev, 64, "fp8", True, dense_scale=70.0)
-    s32, g32_, x32 = res["f32"]
-    s8, g8, x8 = res["fp8"]
-    lines = ["scalars fp32 %s" % np.array2string(s32, precision=4), "scalars fp8  %s" % np.array2string(s8, precision=4),
-             "fake images max |fp8 - fp32| %.4f" % (x8 - x32).abs().max().item()]
-    cosines = {}
-    for n in ("D", "R", "S", "G"):
-        a, b = g32_[n].double(), g8[n].double()
-        cosines[n] = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
-        lines.append("%s gradient cosine %.5f  (|fp8| / |fp32| = %.4f)" % (n, cosines[n], float(b.norm() / (a.norm() + 1e-30))))
-    try:
-        os.makedirs("gpurun_out", exist_ok=True)
-        open("gpurun_out/c5_bs64_tracking.txt", "w").write("\n".join(lines) + "\n")
-    except OSError:
-        pass
-    assert np.all(np.isfinite(s8)), s8
-    assert np.all(np.abs(s8 - s32) <= 0.2 * np.maximum(1.0, np.abs(s32))), (s8, s32)
-    assert (x8 - x32).abs().max().item() <= 0.15
-    for n in ("D", "R", "S", "G"):
-        assert cosines[n] > (0.75 if n == "G" else 0.9), "%s: cosine %.4f" % (n, cosines[n])
+    lines = []
+    for balance in (False, True):
+        res = _step_in_two_modes(NA, dev, 64, "fp8", balance, dense_scale=70.0, z_scale=30.0, spread_styles=True)
+        s32, g32_, x32 = res["f32"]
+        s8, g8, x8 = res["fp8"]
+        rho = (s8[12] / s8[11]) / (s32[12] / s32[11])          # ratio of the balancing factors std(g_loss) / std(r_fake)
+        lines += ["gradient balancing %s" % ("ON" if balance else "OFF"), "  scalars fp32 %s" % np.array2string(s32, precision=4),
+                  "  scalars fp8  %s" % np.array2string(s8, precision=4), "  fake images max |fp8 - fp32| %.4f" % (x8 - x32).abs().max().item(),
+                  "  balancing factor std(g_loss) / std(r_fake): fp8 / fp32 = %.4f" % rho]
+        cos, nrm = {}, {}
+        for n in ("D", "R", "S", "G"):
+            a, b = g32_[n].double(), g8[n].double()
+            cos[n] = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            nrm[n] = float(b.norm() / (a.norm() + 1e-30))
+            lines.append("  %s gradient cosine %.5f  |fp8| / |fp32| = %.4f" % (n, cos[n], nrm[n]))
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            open("gpurun_out/c5_bs64_tracking.txt", "w").write("\n".join(lines) + "\n")
+        except OSError:
+            pass
+        assert np.all(np.isfinite(s8)), s8
+        assert np.all(np.abs(s8 - s32) <= 0.2 * np.maximum(1.0, np.abs(s32))), (s8, s32)
+        assert (x8 - x32).abs().max().item() <= 0.2
+        for n in ("D", "R", "S", "G"):
+            if not balance:
+                assert cos[n] > 0.95 and abs(nrm[n] - 1.0) <= 0.03, "%s (balancing off): cosine %.4f, norm ratio %.4f" % (n, cos[n], nrm[n])
+            else:
+                assert cos[n] > {"G": 0.9, "D": 0.98, "S": 0.98, "R": 0.999}[n], "%s: cosine %.4f" % (n, cos[n])
+        if balance:
+            lo, hi = min(1.0, rho) - 0.05, max(1.0, rho) + 0.05
+            assert lo <= nrm["G"] <= hi, "G: norm ratio %.4f outside [%.3f, %.3f] (balancing-factor ratio %.4f)" % (nrm["G"], lo, hi, rho)
+            assert abs(nrm["D"] - 1.0) <= 0.03 and abs(nrm["S"] - 1.0) <= 0.03 and abs(nrm["R"] - 1.0) <= 0.03, nrm

@@ -221,3 +221,29 @@ def test_pmc_traffic_tool_units_and_gfx950_correction(tmp_path):
     assert d["fetch_bytes_per_launch"] == 2.0 * 2000.0 * 1024.0          # mean 2000 KiB, doubled
     assert d["write_bytes_per_launch"] == 1000.0 * 1024.0
     assert d["traffic_bytes_per_launch"] == d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]
+
+
+def test_loss_plots_from_the_summaries(tmp_path):
+    """utilities.main (/root/reference/src/utilities.py:8-49): per-epoch means of the 16-column batch summary
+    that data_utils.train writes, the reference's four figures on disk, with and without the gradient-balancing curves."""
+    import numpy as np
+    from scrabble_gan_amd import utilities
+    from scrabble_gan_amd.data_utils import SUMMARY_HEADER
+    rng = np.random.default_rng(0)
+    rows = rng.random((7, 16))                      # 7 batches, 3 per epoch: two full epochs and a partial one
+    with open(tmp_path / "batch_summary.txt", "w") as f:
+        f.write(SUMMARY_HEADER)
+        for r in rows:
+            f.write(";".join(repr(float(v)) for v in r) + "\n")
+    names, data = utilities.read_summary(str(tmp_path / "batch_summary.txt"))
+    assert names[:3] == ["d_loss", "d_loss_real", "d_loss_fake"] and names[9] == "g_final_loss" and data.shape == (7, 16)
+    assert np.array_equal(data, rows)
+    means = utilities.per_epoch_means(data, 3)
+    assert means.shape == (3, 16)
+    assert np.allclose(means[0], rows[:3].mean(0)) and np.allclose(means[2], rows[6])
+    for balance, n in ((False, 4), (True, 4)):
+        files = utilities.main(str(tmp_path), 3, info_per_batch=True, gradient_balance=balance)
+        assert len(files) == n
+        for p in files:
+            assert os.path.getsize(p) > 1000 and open(p, "rb").read(4) == b"\x89PNG"
+    assert len(utilities.main(str(tmp_path), 3, info_per_batch=False)) == 3

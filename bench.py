@@ -323,7 +323,9 @@ def roofline_of(res, conv_dtype, world):
                        "timed": "inside the timed region" if res["timing_in_region"] else "%d extra steps after the timed region" % timed_steps}
     out["kernels"] = {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms"] / timed_steps, 3),
                           "launches_per_step": v["launches"] / timed_steps, "peak_tflops": peak_of(k) if not k.endswith("_thin") else None,
-                          "frac_of_mfma_peak": round(v["tflops"] / peak_of(k), 4) if not k.endswith("_thin") else None}
+                          "frac_of_mfma_peak": round(v["tflops"] / peak_of(k), 4) if not k.endswith("_thin") else None,
+                          # every operand read once + every result written once, per launch (beside the PMC `traffic` where measured)
+                          "algorithmic_bytes_per_launch": (v.get("bytes", 0.0) / max(v["launches"], 1)) or None}
                       for k, v in ks.items()}
     for fam in ("wgrad", "wgrad_wino", "igemm"):
         if fam in out["kernels"] and fam != dom:

@@ -135,7 +135,12 @@ _SIDE = {}             # raw handle of the stream that is "main" for a sweep -> 
 CAPTURING = False      # graph_step.GraphedStep sets this while a step is captured into a HIP graph (single stream)
 
 
-STREAMS_LOWP = _os.environ.get("SG_STREAMS_LOWP", "0") == "1"      # (experiment, round 4: the network stream in bf16 / fp8 mode too)
+# Round 4: the network stream in bf16 / fp8 mode too (c3: 1 774 -> 1 836 img/s).  What crosses streams there are the operand copies
+# ("twins") -- made and read inside one network's passes, i.e. on one stream; tensors shared by two networks (x_f, the real images)
+# enter each network's pass through its own concatenated batch, so no copy made on one stream is read on the other before a join --
+# and the fp8 amax slots, pooled per stream (_amax_slot).  tests/test_train_loop_gpu.py::test_network_and_side_streams_do_not_change_
+# the_step[bf16] holds the two-stream step to the single-stream one.  SG_STREAMS_LOWP=0: fp32 mode only, as in round 3.
+STREAMS_LOWP = _os.environ.get("SG_STREAMS_LOWP", "1") == "1"
 
 
 def _streams_ok() -> bool:
@@ -143,7 +148,7 @@ def _streams_ok() -> bool:
 
 
 def side_enabled() -> bool:
-    return SIDE_WGRAD and _streams_ok()
+    return SIDE_WGRAD and _streams_ok() and CONV_DTYPE == "f32"        # (operand copies made for a weight-grad would be read on the sweep's stream)
 
 
 def _side_of_current():
@@ -579,12 +584,13 @@ USE_V2 = _os.environ.get("SG_BF16_V2", "1") == "1"
 _TWINS = {}
 
 
-_AMAX_POOL = {"buf": None, "next": 0}
+_AMAX_POOL = {}        # raw stream handle -> {"buf", "next"}: a pool is zeroed and handed out on ONE stream (its slots are written by that
+                       # stream's conv epilogues and read by that stream's conversion kernels, or behind a join)
 
 
 def _amax_slot(like: torch.Tensor) -> torch.Tensor:
-    """Two zeroed floats (max |t|, max |scale t|) from a per-step pool: ONE memset launch per 1024 convolutions."""
-    pool = _AMAX_POOL
+    """Two zeroed floats (max |t|, max |scale t|) from a per-step, per-stream pool: ONE memset launch per 1024 convolutions."""
+    pool = _AMAX_POOL.setdefault(_stream(), {"buf": None, "next": 0})
     if pool["buf"] is None or pool["next"] + 2 > pool["buf"].numel() or pool["buf"].device != like.device:
         pool["buf"] = torch.zeros(2048, device=like.device)
         pool["next"] = 0
@@ -616,7 +622,7 @@ def _amax_get(t: torch.Tensor, scale=None, need_scaled: bool = False):
 def new_step() -> None:
     _TWINS.clear()
     _GHOSTS.clear()
-    _AMAX_POOL["buf"] = None
+    _AMAX_POOL.clear()
     _WINO_V["map"].clear()
     _WINO_V["on"] = WINO_KEEP_V
 

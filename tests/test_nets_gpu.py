@@ -462,47 +462,18 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
     assert len(out) == 16 and out[10] == 1
     for i, (a, b) in enumerate(zip(out, ref_scalars)):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), "scalar %d: %r vs %r (oracle fp32 deviates by %.1e)" % (i, a, b, cal["scalar_err32"][i])
-    report, bad, bounds, flips, exempted = [], [], {}, [], []
-    for net in ("D", "R", "S", "G"):
-        model = models[net]
-        at = net_atol(list(ref_grads[net].values()))
-        for k, v in ref_grads[net].items():
-            scale = v.abs().max().item()
-            diff = (model.store.g[k].detach().double().cpu() - v).abs()
-            err = diff.max().item()
-            e32 = cal["err32"][net][k]
-            bound = max(3.0 * e32, 1e-3 * scale) + at
-            bounds[(net, k)] = (bound, diff <= bound)
-            report.append((err / (scale + 1e-30), e32 / (scale + 1e-30), net, k))
-            # whole-tensor (L2) criterion, same calibration
-            # (tensors of fewer than 64 elements -- NonLocalBlock sigma: ONE cancelling sum over all pixels -- have no
-            #  "isolated outlier" notion: they are held to max(10 x the oracle's fp32 deviation, 2 % of their value) instead)
-            l2, l2_ref, l2_32 = diff.norm().item(), v.norm().item(), cal["l2err32"][net][k]
-            if v.numel() < 64:
-                if not err <= max(10.0 * e32, 2e-2 * scale) + at:
-                    bad.append("%s grad %s (small tensor): |HIP-fp64| %.3e, oracle fp32 %.3e, scale %.3e" % (net, k, err, e32, scale))
-                continue
-            if not l2 <= max(3.0 * l2_32, 1e-3 * l2_ref) + at * math.sqrt(max(v.numel(), 1)):
-                bad.append("%s grad %s: ||HIP-fp64||_2 %.3e vs oracle fp32 %.3e, ||ref||_2 %.3e" % (net, k, l2, l2_32, l2_ref))
-            if not err <= bound:
-                # ReLU / max-pool DECISIONS: a pre-activation within fp32 rounding of zero may fall on the other side than in
-                # fp64 (for the oracle's fp32 evaluation as well, at other elements).  One flipped element of a
-                # ConditionalBatchNorm over 32 pixels per sample moves one column of dgamma / dbeta and one 32-entry row of
-                # the filter-bank gradient by a few percent and nothing else; one flipped activation in front of a 3x3 conv of
-                # D / S / R moves up to 9 x Cout entries of that conv's weight gradient.  Such outliers are admitted ONLY through
-                # the counterfactual oracle below, which has to reproduce them.
-                n_out = int((diff > bound).sum().item())
-                flips.append("%s.%s: %d element(s) above the bound, max %.3e (bound %.3e)" % (net, k, n_out, err, bound))
-                exempted.append((net, k, bound, at))        # (any network, any count: the counterfactual below decides)
-    # ---- proof of the outlier exemption.  (1) Every ReLU / max-pool decision of the HIP passes -- all 75 ReLU and 22 MaxPool2D
-    # sites of the step: G, both D calls, the three S calls, both R calls -- that
-    # differs from the fp64 oracle's must sit within fp32 rounding of the boundary: |fp64 pre-activation| (resp. the gap between
-    # the chosen window element and the window maximum) <= 2e-5 x the site's largest value (checked whether or not a tensor
-    # needed the exemption -- a decision that differs AWAY from the boundary is a wrong activation, not rounding).  (2) The fp64
-    # oracle is re-evaluated with exactly those decisions imposed (the counterfactual: y = x * HIP's mask at the flipped ReLU
-    # sites, y = HIP's window element at the flipped MaxPool2D sites, backward routing included); against IT every tensor that
-    # had outliers -- of any network, however many elements -- must meet its calibrated bound at ALL elements.  An indexing
-    # error survives neither, whatever the number of elements it touches.
+    # ---- (1) the DECISIONS.  Every ReLU / max-pool decision of the HIP passes -- all 75 ReLU and 22 MaxPool2D sites of the step: G,
+    # both D calls, the three S calls, both R calls -- that differs from the fp64 oracle's must sit within fp32 rounding of the
+    # boundary: |fp64 pre-activation| (resp. the gap between the chosen window element and the window maximum) <= 2e-5 x the
+    # site's largest value.  A decision that differs AWAY from the boundary is a wrong activation, not rounding.
+    # ---- (2) the VALUES.  If any decision differs, the reference for every gradient tensor below is the COUNTERFACTUAL fp64
+    # oracle: re-evaluated with exactly HIP's decisions imposed at the differing sites (y = x * HIP's mask, resp. HIP's window
+    # element; backward routing included).  A flipped near-tie moves single elements of the gradients behind it by O(1) -- for any
+    # fp32 evaluation, the oracle's own included (at other elements) -- so neither the max-norm nor the L2 bound can be asked of
+    # the plain oracle then (round 4: three flips at |pre-activation| ~ 1e-8 in one run of the c4 problem, none in the next;
+    # the L2 criterion of G.final.w failed against the plain oracle at 1.7e-3 and holds at 1e-6 against the counterfactual).
+    # An indexing error survives neither check, whatever the number of elements it touches.
+    report, bad, flips, bounds = [], [], [], {}
     sites64, pools64 = cal["relu_sites64"], cal["pool_sites64"]
     forced, forced_pool, n_flip = {}, {}, 0
     for i, dec in sorted(hip_relu.items()):
@@ -532,17 +503,36 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
                 bad.append("MaxPool site %d: a selection differs from the fp64 oracle by %.3e > %.3e (not a rounding flip)" % (i, far, lim))
             forced_pool[i] = idx
         n_flip += nf
-    if exempted:
-        if n_flip == 0:
-            bad.append("outliers in %s but NO ReLU / max-pool decision of the step differs from fp64: not a decision flip" % [k for _, k, _, _ in exempted])
-        else:
-            _, g_cf, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced, forced_pool=forced_pool)
-            for net, k, bound, at in exempted:
-                d_cf = (models[net].store.g[k].detach().double().cpu() - g_cf[net][k]).abs()
-                n_cf = int((d_cf > bound).sum().item())
-                flips.append("%s.%s vs the counterfactual oracle (HIP's decisions imposed): max %.3e, %d element(s) above the bound %.3e" % (net, k, d_cf.max().item(), n_cf, bound))
-                if n_cf:
-                    bad.append("%s grad %s: %d outlier(s) remain against the counterfactual oracle (max %.3e > bound %.3e): not explained by the decision flips" % (net, k, n_cf, d_cf.max().item(), bound))
+    check_grads, which = ref_grads, "fp64 oracle"
+    if n_flip:
+        _, check_grads, _, _ = F.run_oracle(pb, torch.float64, loss_name, balance, forced=forced, forced_pool=forced_pool)
+        which = "counterfactual fp64 oracle (%d differing near-tie decisions imposed)" % n_flip
+    flips.append("gradients are held to the %s" % which)
+    for net in ("D", "R", "S", "G"):
+        model = models[net]
+        at = net_atol(list(ref_grads[net].values()))
+        for k, v in check_grads[net].items():
+            scale = ref_grads[net][k].abs().max().item()
+            diff = (model.store.g[k].detach().double().cpu() - v).abs()
+            err = diff.max().item()
+            e32 = cal["err32"][net][k]
+            bound = max(3.0 * e32, 1e-3 * scale) + at
+            # (for the post-Adam comparison below, whose reference weights come from the plain oracle: the elements no flip touched)
+            bounds[(net, k)] = (bound, (model.store.g[k].detach().double().cpu() - ref_grads[net][k]).abs() <= bound)
+            report.append((err / (scale + 1e-30), e32 / (scale + 1e-30), net, k))
+            margins.record("%s grad %s" % (net, k), err / (bound / 1e-3 + 1e-30), 1e-3)
+            # whole-tensor (L2) criterion, same calibration
+            # (tensors of fewer than 64 elements -- NonLocalBlock sigma: ONE cancelling sum over all pixels -- are held to
+            #  max(10 x the oracle's fp32 deviation, 2 % of their value) instead)
+            l2, l2_ref, l2_32 = diff.norm().item(), v.norm().item(), cal["l2err32"][net][k]
+            if v.numel() < 64:
+                if not err <= max(10.0 * e32, 2e-2 * scale) + at:
+                    bad.append("%s grad %s (small tensor): |HIP-ref| %.3e, oracle fp32 %.3e, scale %.3e" % (net, k, err, e32, scale))
+                continue
+            if not l2 <= max(3.0 * l2_32, 1e-3 * l2_ref) + at * math.sqrt(max(v.numel(), 1)):
+                bad.append("%s grad %s: ||HIP-ref||_2 %.3e vs oracle fp32 %.3e, ||ref||_2 %.3e (%s)" % (net, k, l2, l2_32, l2_ref, which))
+            if not err <= bound:
+                bad.append("%s grad %s: %d element(s) above the bound, max %.3e (bound %.3e) against the %s" % (net, k, int((diff > bound).sum().item()), err, bound, which))
     # what the calibration looked like (kept by gpurun under gpurun_out/ for DESIGN.md)
     try:
         import os

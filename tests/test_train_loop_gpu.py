@@ -356,8 +356,11 @@ def test_graph_captured_step_equals_eager_steps(dev, mode):
         assert diff.max().item() <= 4 * 2e-4 and diff.mean().item() <= 5e-6, (m.name, diff.max().item(), diff.mean().item())
 
 
-def test_network_and_side_streams_do_not_change_the_step(dev):
-    """Small per-GPU batches queue S's passes on a second stream beside D's / R's (ops.net_stream) and every weight-grad launch on
+@pytest.mark.parametrize("conv_dtype", ["f32", "bf16", "fp8"])
+def test_network_and_side_streams_do_not_change_the_step(dev, conv_dtype):
+    """(bf16 / fp8, round 4: the network stream alone -- the weight-grad side streams are an fp32-mode option -- with the operand
+    copies and the per-stream amax pools in play; same criterion.)
+    Small per-GPU batches queue S's passes on a second stream beside D's / R's (ops.net_stream) and every weight-grad launch on
     a side stream of its sweep (ops.side_stream).  The same step (the B = 8 fixture, all passes fused, no gradient balancing) with
     both switched off must give the same 16 scalars (1e-5) and the same gradients of all four networks -- a missing event / join
     would show as stale or partial gradients.  Yardstick = the run-to-run noise of the SINGLE-stream step itself (two runs: float
@@ -373,10 +376,13 @@ def test_network_and_side_streams_do_not_change_the_step(dev):
     B = pb["B"]
     res = {}
     old = (ops.NET_STREAM, ops.SIDE_WGRAD)
-    lib().sg_set_deterministic(1)
+    if conv_dtype == "f32":       # (bf16 / fp8: the 64 -> 64 weight-grad has no one-adder form on the second-generation kernels; the yardstick covers the atomics)
+        lib().sg_set_deterministic(1)
+    ops.set_conv_dtype(conv_dtype)
     try:
         for mode, on in (("streams", True), ("single", False), ("single2", False)):
-            ops.NET_STREAM = ops.SIDE_WGRAD = on
+            ops.NET_STREAM = on
+            ops.SIDE_WGRAD = on and conv_dtype == "f32"
             assert ops.net_stream_enabled(3 * B) == on
             NA._model_counter[0] = 0
             NA.configure(device=dev, seed=9)
@@ -395,22 +401,36 @@ def test_network_and_side_streams_do_not_change_the_step(dev):
     finally:
         ops.NET_STREAM, ops.SIDE_WGRAD = old
         lib().sg_set_deterministic(0)
+        ops.set_conv_dtype("f32")
     sa, ga = res["streams"]
     sb, gb = res["single"]
-    _, gc = res["single2"]
-    assert np.all(np.abs(sa - sb) <= 1e-5 * np.maximum(1.0, np.abs(sb))), (sa, sb)
+    sc, gc = res["single2"]
+    # Floors of the criterion |streams - single| <= max(floor, 4 x |single - single'|): fp32 -- the conv kernels run one adder per
+    # address here, what is left is float-atomic BatchNorm / filter-bank / attention partial sums: 1e-5 of a scalar, 3e-4 of a
+    # network's largest gradient.  bf16 / fp8 -- the reduction-split tiles of the convolutions meet through float atomics in a
+    # run-dependent order and every result is re-quantised for the next launch, so two SINGLE-stream runs already differ at the
+    # operand precision (measured: scalars 1e-4 / 3e-2 relative, profiles/r04_streams_vs_single_{bf16,fp8}.txt): 2e-3 / 5e-2 of a
+    # scalar, 2e-2 / 1e-1 of the largest gradient.  A missing event or join reads operand copies that are not written yet --
+    # errors of the order of the values themselves -- and stays far outside either.
+    s_floor, g_floor = {"f32": (1e-5, 3e-4), "bf16": (2e-3, 2e-2), "fp8": (5e-2, 1e-1)}[conv_dtype]
     lines, bad = [], []
+    for i in range(16):
+        lines.append("scalar %2d: streams %.6e  single %.6e  single' %.6e" % (i, sa[i], sb[i], sc[i]))
+        if abs(sa[i] - sb[i]) > max(s_floor * max(1.0, abs(sb[i])), 4.0 * abs(sb[i] - sc[i])):
+            bad.append(lines[-1])
+    glines = []
     for n in ("D", "R", "S", "G"):
         scale = max(t.abs().max().item() for t in gb[n].values())
         for k in gb[n]:
             err = (ga[n][k] - gb[n][k]).abs().max().item()
             noise = (gb[n][k] - gc[n][k]).abs().max().item()
-            lines.append("%s.%s: |streams - single| %.3e  |single - single'| %.3e  (largest gradient of the network %.3e)" % (n, k, err, noise, scale))
-            if err > max(3e-4 * scale, 4.0 * noise):
-                bad.append(lines[-1])
+            glines.append("%s.%s: |streams - single| %.3e  |single - single'| %.3e  (largest gradient of the network %.3e)" % (n, k, err, noise, scale))
+            if err > max(g_floor * scale, 4.0 * noise):
+                bad.append(glines[-1])
     try:
         os.makedirs("gpurun_out", exist_ok=True)
-        open("gpurun_out/streams_vs_single.txt", "w").write("\n".join(sorted(lines, key=lambda l: -float(l.split("|streams - single| ")[1].split()[0]))[:40]) + "\n")
+        open("gpurun_out/streams_vs_single%s.txt" % ("" if conv_dtype == "f32" else "_" + conv_dtype), "w").write(
+            "\n".join(lines + sorted(glines, key=lambda l: -float(l.split("|streams - single| ")[1].split()[0]))[:40]) + "\n")
     except OSError:
         pass
     assert not bad, "\n".join(bad[:10])

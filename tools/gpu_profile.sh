@@ -8,8 +8,13 @@ O=$R/${1:-gpurun_out/prof}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --no-cpu-baseline --no-kernel-timing --no-extra-configs"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats128 -o run -- python3 $B --steps 2 --warmup 1 > $O/stats128.log 2>&1
+# (round 4) the production path runs S's passes on a second stream: a kernel's duration in THAT trace includes the time it shares the chip.
+# stats128 = one stream (SG_NET_STREAM=0): each kernel has the GPU to itself -- the durations bench.py's roofline is computed from;
+# stats128_streams = the default two-stream schedule (what the timed region runs).
+SG_NET_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats128 -o run -- python3 $B --steps 2 --warmup 1 > $O/stats128.log 2>&1
 echo stats128 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats128_streams -o run -- python3 $B --steps 2 --warmup 1 > $O/stats128_streams.log 2>&1
+echo stats128_streams done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats16 -o run -- python3 $B --steps 4 --warmup 2 --batch 16 > $O/stats16.log 2>&1
 echo stats16 done
 if [ -z "$ONLY_F32" ]; then
@@ -18,6 +23,7 @@ echo stats_bf16 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp8 -o run -- python3 $B --steps 2 --warmup 1 --conv-dtype fp8 --batch 512 --balance > $O/stats_fp8.log 2>&1
 echo stats_fp8 done
 fi
+export SG_NET_STREAM=0      # counter passes: one stream (the counters are per dispatch; overlapped dispatches would share them)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_fetch.log 2>&1
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $B --steps 1 --warmup 1 > $O/pmc_write.log 2>&1

@@ -442,7 +442,7 @@ def check_step_against_calibrated_oracle(NA, dev, pb, loss_name, balance, tag, b
     """Run one train_step through the HIP path on problem `pb` and hold it to the calibrated bound (see test_train_step)."""
     from tests import step_fixture as F
     from scrabble_gan_amd import data_utils as DU, net_loss, optimizers
-    cal = F.calibrate(pb, loss_name, balance)
+    cal = F.calibrate(pb, loss_name, balance, tag=tag)
     ref_scalars, ref_grads, ref_w = cal["scalars"], cal["grads"], cal["weights"]
     assert ref_scalars[12] > 0.05 and ref_scalars[11] > 0.05, "fixture lost its conditioning: std(g_loss), std(r_fake) = %r" % (ref_scalars[11:13],)
 

@@ -287,6 +287,10 @@ def nonlocal_weights(C: int, gen: torch.Generator, device) -> Dict[str, torch.Te
             "g": orthogonal((1, 1, C, C // 2), gen).to(device), "o": orthogonal((1, 1, C // 2, C), gen).to(device)}
 
 
+_NL_RING = 4
+_NL_RINGS: Dict = {}
+
+
 def nonlocal_weights_batch(requests, device) -> List[Dict[str, torch.Tensor]]:
     """Draw the kernels of several NonLocalBlock calls at once: QR on the host, ONE pinned staging buffer and
     ONE asynchronous H2D copy, so the per-call re-draw of the reference (fact 3) costs no mid-step host sync.
@@ -305,12 +309,30 @@ def nonlocal_weights_batch(requests, device) -> List[Dict[str, torch.Tensor]]:
         torch.set_num_threads(nthreads)
     flat = torch.cat(host)
     if device.type == "cuda":
-        # staging buffer from torch's caching host allocator (reused across steps, guarded by its own events);
-        # Tensor.pin_memory() instead is a fresh hipHostMalloc per call: ~15 ms of host time per step
-        pinned = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
-        pinned.copy_(flat)
-        flat = pinned
-    dev = flat.to(device, non_blocking=True)
+        # A ring of persistent (pinned staging buffer, device buffer, event) slots per payload size.  Round 4: the former
+        # `torch.empty(pin_memory=True)` + `.to(device, non_blocking=True)` pair cost the HOST 20-30 ms per step at the shard batch
+        # (tools/host_profile.py, profiles/r04_host_profile_bs16.txt: the copy waited behind the whole queued step) -- the eager
+        # shard step ran 37.2 ms where its graph replay, which uploads through persistent buffers, ran 33.8 ms.  A slot is reused
+        # _NL_RING steps later; by then its copy has long completed (the event wait below is a formality) and every kernel that read
+        # the device buffer was queued before the copy that overwrites it (one launch stream; the network stream joins it each step).
+        key = (flat.numel(), device.index)
+        ring = _NL_RINGS.get(key)
+        if ring is None:
+            ring = _NL_RINGS[key] = {"next": 0, "slots": [
+                {"pinned": torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True),
+                 "dev": torch.empty(flat.numel(), dtype=torch.float32, device=device), "event": None} for _ in range(_NL_RING)]}
+        slot = ring["slots"][ring["next"] % _NL_RING]
+        ring["next"] += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        slot["pinned"].copy_(flat)
+        slot["dev"].copy_(slot["pinned"], non_blocking=True)
+        if slot["event"] is None:
+            slot["event"] = torch.cuda.Event()
+        slot["event"].record(torch.cuda.current_stream(device))
+        dev = slot["dev"]
+    else:
+        dev = flat.to(device)
     out, off, idx = [], 0, 0
     for _ in requests:
         d = {}

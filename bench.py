@@ -115,7 +115,7 @@ def dry_run(args):
 
 
 WORKLOADS = {
-    "f32": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs, hinge, disc_iters=1",
+    "f32": "c2: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp32 MFMA convs (3x3 over >= 64 channels as F(4x4,3x3) Winograd-domain products: exact fp32 products, fp32 accumulation), hinge, disc_iters=1",
     "bf16": "c3: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, bf16 MFMA convs (fp32 accumulation, bf16 operand copies in HBM), hinge, disc_iters=1",
     "fp8": "c5: synthetic random_words 32x160, global bs %d, L_r=L_f=%d, fp8 convs of G/D/S (e4m3 forward / data-grad operands, e4m3 x e5m2 weight-grads, >= 128 channels), bf16 recognizer + CTC, hinge",
 }
@@ -466,6 +466,7 @@ def main():
                                        "multiples of 4, F(2x2,3x3) at 16/36 otherwise (conv_winograd.hip) -- so these rates may exceed the fp32 MFMA peak.  roofline.achieved and kernels.* count the "
                                        "products the matrix cores EXECUTE (Winograd-domain products for those launches) over HIP-event time")
         line["config"]["hip_graph"] = bool(args.graph)
+        line["config"]["streams"] = "S's passes on a second HIP stream beside D's and R's (timed region); per-kernel timing on one stream"
         line["config"]["fused_passes"] = True
         line["config"]["shared_backward"] = True
         line["rccl_ranks"] = torch.distributed.get_world_size() if world > 1 else 1

@@ -156,16 +156,22 @@ constexpr int SG2_LDS = 4 * SG2_TILE;                         // A stage 0 | A s
 // BMT = rows of the A tile: 256 (8 waves, one workgroup per CU) or 128 with BN = 128 (round 3: 4 waves as 2 x 2 of 64 x 64 wave
 // tiles, 64 KB of LDS -> TWO workgroups per CU: the HBM-bound epilogue of one overlaps the k-loop of the other; the 64-filter
 // configuration, which sits at two per CU already, loses 35-45 % when forced down to one: profiles/r03_probe_occupancy64.txt)
-template <int BN, int ES, bool RELU, int BMT = 256>
-__global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
+// NWO (round 4) = waves per workgroup when it is not the tile's default (0): the fp32 128 x 128 tile with EIGHT waves of 32 x 64
+// (four per SIMD at two workgroups per CU, 128 VGPRs each): a lone wave cannot keep the fp32 matrix pipe full through its own
+// fragment waits and the k-tile barrier, so while one workgroup is in its prologue / epilogue the other's waves left the pipe
+// 20-25 % idle (MFMA busy 78.5 % at K = 512 against 84.8 % at K = 1024, profiles/r04_probe_clock_bs128.txt).
+template <int BN, int ES, bool RELU, int BMT = 256, int NWO = 0>
+__global__ __launch_bounds__((NWO ? NWO : (BMT == 256 ? 8 : 4)) * 64, 2) void sg_igemm_bf16v2_kernel(const SgIgemm2Args p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   constexpr int BM = BMT, BK = 128 / ES;               // channels per k-tile
-  constexpr int NW = BM == 256 ? 8 : 4;                 // waves per workgroup
+  constexpr int NW = NWO ? NWO : (BM == 256 ? 8 : 4);   // waves per workgroup
   constexpr int ATILE = BM * 128;                       // bytes of an A stage
   constexpr int WN = BN / 64, WM = NW / WN;             // waves along n / m
   constexpr int TM = BM / WM / 32, TN = 2;              // 32 x 32 MFMA tiles per wave
   constexpr int BQ = BN / (8 * NW);                     // B-tile DMA instructions per thread
+  constexpr int AQ = BM / (8 * NW);                     // A-tile DMA instructions per thread (4, or 2 with eight waves on 128 rows)
   static_assert(BM == 256 || (BM == 128 && BN == 128), "tile configurations");
+  static_assert(NWO == 0 || (NWO == 8 && BM == 128 && ES == 4), "eight waves: the fp32 128 x 128 tile only");
   constexpr int BTILE = BN * 128;                       // bytes of the B tile
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -265,7 +271,8 @@ __global__ __launch_bounds__(BMT == 256 ? 512 : 256, 2) void sg_igemm_bf16v2_ker
     const unsigned char* src_b = reinterpret_cast<const unsigned char*>((uintptr_t)pb);
     unsigned char* dst_a = smem + st * ATILE + (NW * q + wave) * 1024;
     unsigned char* dst_b = smem + 2 * ATILE + st * BTILE + (NW * q + wave) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a, (__attribute__((address_space(3))) void*)dst_a, 16, 0, 0);
+    if (q < AQ)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a, (__attribute__((address_space(3))) void*)dst_a, 16, 0, 0);
     if (q < BQ)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_b, (__attribute__((address_space(3))) void*)dst_b, 16, 0, 0);
   };
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(256) void k_amax_rows(const float* __restrict__ x, 
 static int g2_split_override = -1;
 extern "C" void sg_debug_set_splitk_v2(int n) { g2_split_override = n; }
 
-template <int BN, int ES, bool RELU, int BMT = 256>
+template <int BN, int ES, bool RELU, int BMT = 256, int NWO = 0>
 static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) {
   const long M = (long)a.Bn * a.Hg * a.Wg;
   const int n_tiles = a.N / BN;
@@ -751,13 +758,13 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   static const int lds_pad = getenv("SG2_LDS_PAD") ? atoi(getenv("SG2_LDS_PAD")) : 0;      // (occupancy probe: extra bytes requested, never touched)
   const int LDS_BYTES = 2 * BMT * 128 + 2 * BN * 128 + lds_pad;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT, NWO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return SG_ERR_UNSUPPORTED;
     }
     attr_done = true;
   }
-  SG_KERNEL((sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT>), dim3(full + (tiles - full) * nsplit), dim3(BMT == 256 ? 512 : 256), LDS_BYTES, s, a);
+  SG_KERNEL((sg_igemm_bf16v2_kernel<BN, ES, RELU, BMT, NWO>), dim3(full + (tiles - full) * nsplit), dim3((NWO ? NWO : (BMT == 256 ? 8 : 4)) * 64), LDS_BYTES, s, a);
   if (twin_rows_done) *twin_rows_done = (a.flags & SG2_IDENT_OUT) ? row0 : (nsplit > 1 ? 0 : M);
   if (a.amax_out && nsplit > 1) {
     // the split tiles' values are final only now: their amax comes from a sweep over those rows (identity layouts: the rows
@@ -771,10 +778,10 @@ static int sg2_launch_bn_r(SgIgemm2Args a, hipStream_t s, long* twin_rows_done) 
   return sg_launch_status();
 }
 
-template <int BN, int ES, int BMT = 256>
+template <int BN, int ES, int BMT = 256, int NWO = 0>
 static int sg2_launch_bn(const SgIgemm2Args& a, hipStream_t s, long* twin_rows_done) {
   if constexpr (ES == 1) return sg2_launch_bn_r<BN, ES, false, BMT>(a, s, twin_rows_done);     // (fp8: the ReLU is applied by the fp8 convert)
-  else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true, BMT>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false, BMT>(a, s, twin_rows_done);
+  else return (a.flags & SG_RELU_IN) ? sg2_launch_bn_r<BN, ES, true, BMT, NWO>(a, s, twin_rows_done) : sg2_launch_bn_r<BN, ES, false, BMT, NWO>(a, s, twin_rows_done);
 }
 
 // SG2_TILE128 / sg_debug_set_tile128: 0 = never (default), 1 = the rule below, 2 = whenever the filter count is a multiple of 128
@@ -828,6 +835,13 @@ int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_r
   if (es == 4) {
     // grouped launches (Winograd-domain products): 128 x 128 tiles, two workgroups per CU -- level with the 256-row tiles on the
     // large launches (profiles/r03_probe_winograd.txt: 10.49 vs 10.58 ms, 8.67 vs 8.65 ms) and half the plane padding on the small ones
+    // (round 4) eight waves per 128 x 128 tile (NWO = 8) on launches of fewer than eight rounds of the chip's 512 workgroup slots -- the
+    // shard batch: +8-20 % on its small planes, 34.1 -> 33.3 ms per step (profiles/r04_probe_w8.txt).  On the headline batch the variant is
+    // +3 % in isolation but -0.7 % in the two-stream step (its four waves per SIMD hold 492 of the 512 VGPRs: no room for the other
+    // network's HBM-bound waves beside it), so large launches keep four waves.  SG2_W8 = 0: never, 2: always.
+    static const int w8 = getenv("SG2_W8") ? atoi(getenv("SG2_W8")) : 1;
+    const long g_tiles = (long)sg_cdiv((long)a.Bn * a.Hg * a.Wg, 128) * (a.N / 128);
+    if (a.group_rows && (w8 == 2 || (w8 == 1 && g_tiles < 8 * 512))) return a.N % 128 == 0 ? sg2_launch_bn<128, 4, 128, 8>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;
     if (a.group_rows) return a.N % 128 == 0 ? sg2_launch_bn<128, 4, 128>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;
     if (bn == 256) return sg2_launch_bn<256, 4>(a, s, twin_rows_done);
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);

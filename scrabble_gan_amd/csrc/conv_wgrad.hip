@@ -319,6 +319,8 @@ int sg_launch_wgrad(const SgWgradArgs& a_in, hipStream_t s) {
   a.q_bytes = (unsigned)(4 * q_elems);
   const bool c_small = a.Cp <= 64, n_small = a.Cq <= 64;
   // (BK = 32 k-tiles at 2 workgroups per CU were measured earlier and dropped: 16 at 3-4 per CU is faster everywhere)
+  static const int w8 = getenv("SG_WGRAD_W8") ? atoi(getenv("SG_WGRAD_W8")) : 0;      // (round 4 experiment) eight waves of 32 x 64 per 128 x 128 tile, two workgroups per CU
+  if (!c_small && !n_small && w8 && (w8 == 2 || a.p_plane > 0)) return launch_wgrad_cfg<128, 128, 4, 2, 16, 2>(a, s);
   if (!c_small && !n_small) return launch_wgrad_cfg<128, 128, 2, 2, 16, 3>(a, s);
   if (!c_small) return launch_wgrad_cfg<128, 64, 2, 2, 16, 4>(a, s);
   if (!n_small) return launch_wgrad_cfg<64, 128, 2, 2, 16, 4>(a, s);

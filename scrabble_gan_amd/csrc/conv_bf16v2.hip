@@ -170,7 +170,7 @@ __global__ __launch_bounds__((NWO ? NWO : (BMT == 256 ? 8 : 4)) * 64, 2) void sg
   constexpr int TM = BM / WM / 32, TN = 2;              // 32 x 32 MFMA tiles per wave
   constexpr int BQ = BN / (8 * NW);                     // B-tile DMA instructions per thread
   constexpr int AQ = BM / (8 * NW);                     // A-tile DMA instructions per thread (4, or 2 with eight waves on 128 rows)
-  static_assert(BM == 256 || (BM == 128 && BN == 128), "tile configurations");
+  static_assert(BM == 256 || (BM == 128 && (BN == 128 || (BN == 64 && ES == 4))), "tile configurations");      // (128 x 64: the grouped fp32 products of 64-filter layers, round 4)
   static_assert(NWO == 0 || (NWO == 8 && BM == 128 && ES == 4), "eight waves: the fp32 128 x 128 tile only");
   constexpr int BTILE = BN * 128;                       // bytes of the B tile
   const int tid = threadIdx.x;
@@ -841,8 +841,9 @@ int sg_launch_igemm_bf16v2(const SgIgemm2Args& a_in, hipStream_t s, long* twin_r
     // network's HBM-bound waves beside it), so large launches keep four waves.  SG2_W8 = 0: never, 2: always.
     static const int w8 = getenv("SG2_W8") ? atoi(getenv("SG2_W8")) : 1;
     const long g_tiles = (long)sg_cdiv((long)a.Bn * a.Hg * a.Wg, 128) * (a.N / 128);
-    if (a.group_rows && (w8 == 2 || (w8 == 1 && g_tiles < 8 * 512))) return a.N % 128 == 0 ? sg2_launch_bn<128, 4, 128, 8>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;
-    if (a.group_rows) return a.N % 128 == 0 ? sg2_launch_bn<128, 4, 128>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;
+    if (a.group_rows && a.N % 128 == 0 && (w8 == 2 || (w8 == 1 && g_tiles < 8 * 512))) return sg2_launch_bn<128, 4, 128, 8>(a, s, twin_rows_done);
+    if (a.group_rows && a.N % 128) return a.N % 64 == 0 ? sg2_launch_bn<64, 4, 128>(a, s, twin_rows_done) : SG_ERR_UNSUPPORTED;      // (64-filter layers: 128 x 64 tiles, three workgroups per CU)
+    if (a.group_rows) return sg2_launch_bn<128, 4, 128>(a, s, twin_rows_done);
     if (bn == 256) return sg2_launch_bn<256, 4>(a, s, twin_rows_done);
     if (bn == 128) return sg2_launch_bn<128, 4>(a, s, twin_rows_done);
     return sg2_launch_bn<64, 4>(a, s, twin_rows_done);

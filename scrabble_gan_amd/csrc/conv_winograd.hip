@@ -525,7 +525,7 @@ extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int 
 
 extern "C" int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, int tile, void* stream) {
   if (!V || !u || !Mt) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N, tile) || (N % 128)) return SG_ERR_UNSUPPORTED;
+  if (!wino_shape_ok(B, H, W, K, N, tile)) return SG_ERR_UNSUPPORTED;          // (N % 64 == 0: 128-wide tiles, or 64-wide for the 64-filter layers)
   const long Tp = wino_tp(wino_tiles(B, H, W, tile));
   const int F = wino_planes(tile);
   if (F * Tp >= (1L << 31) - 256) return SG_ERR_UNSUPPORTED;
@@ -559,7 +559,7 @@ extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, cons
 static int wino_conv(const float* a, const float* u, const float* bias, const float* bias2, const float* mask, float* out, int B, int H, int W,
                      int K, int N, int flags, int tile, void* workspace, long workspace_bytes, hipStream_t s) {
   if (!a || !u || !out || !workspace) return SG_ERR_ARG;
-  if (!wino_shape_ok(B, H, W, K, N, tile) || (N % 128) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
+  if (!wino_shape_ok(B, H, W, K, N, tile) || (flags & SG_TANH_OUT)) return SG_ERR_UNSUPPORTED;
   if (workspace_bytes < sg_wino_workspace_bytes(B, H, W, K, N, tile)) return SG_ERR_ARG;
   const long Tp = wino_tp(wino_tiles(B, H, W, tile));
   float* V = reinterpret_cast<float*>(workspace);

@@ -792,6 +792,9 @@ def _wino_tile(H: int, W: int) -> int:
 # products, not fewer.  The Winograd path is taken only where its padded row count is below WINO_ROW_GAIN x the direct form's (its
 # products run at ~0.75 of the direct loop's rate per row: short reductions); 0 switches the criterion off (the kernels' own tests).
 WINO_ROW_GAIN = float(_os.environ.get("SG_WINO_ROW_GAIN", "0.75"))
+# output channels of a Winograd-domain forward / data-grad launch: a multiple of 64 (round 4: 128 x 64 tiles of the grouped product for the
+# 64-filter layers -- the 512 -> 64 data-grads of the D-shaped trunks ran direct at 131 TF/s, 4x the products; SG_WINO_N_MULT=128: as in round 3)
+WINO_N_MULT = int(_os.environ.get("SG_WINO_N_MULT", "64"))
 
 
 def _wino_rows_ok(B, H: int, W: int, tile: int) -> bool:
@@ -802,7 +805,7 @@ def _wino_rows_ok(B, H: int, W: int, tile: int) -> bool:
 
 
 def _wino_ok(K: int, N: int, kh: int, kw: int, same: bool, H: int, W: int, B=None) -> bool:
-    if not (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0 and K % 32 == 0 and N % 128 == 0):
+    if not (USE_WINOGRAD and CONV_DTYPE == "f32" and kh == 3 and kw == 3 and same and H % 2 == 0 and W % 2 == 0 and K % 32 == 0 and N % WINO_N_MULT == 0):
         return False
     t = _wino_tile(H, W)
     return min(K, N) >= WINO_MIN_C[t] and K * N >= WINO_MIN_KN[t] and _wino_rows_ok(B, H, W, t)

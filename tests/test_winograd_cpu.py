@@ -82,16 +82,17 @@ def test_workspace_arithmetic_of_the_c_abi():
 
 def test_routing_of_the_step_s_convolutions():
     """Which launches of the fp32 step leave the direct kernels (ops._wino_ok / _wino_wgrad_ok / _wino_tile): the D-shaped trunks'
-    3x3 convolutions from 64 -> 512 up and the recognizer's from 128 channels; never 1x1, VALID, odd shapes, <= 64 filters
+    3x3 convolutions from 64 -> 512 up (and back: 512 -> 64) and the recognizer's from 128 channels; never 1x1, VALID, odd shapes, 64 -> 64
     (forward / data-grad) or another operand type; F(2x2) where W is not a multiple of 4 (odd word lengths of the bucketed widths)."""
     from scrabble_gan_amd import ops
     assert ops.CONV_DTYPE == "f32" and ops.USE_WINOGRAD and ops.WINO_TILE == 4
-    yes = [(512, 512, 16, 80), (512, 1024, 8, 40), (1024, 1024, 4, 20), (64, 512, 16, 80), (256, 256, 8, 80), (128, 128, 16, 160), (128, 256, 8, 40)]
+    yes = [(512, 512, 16, 80), (512, 1024, 8, 40), (1024, 1024, 4, 20), (64, 512, 16, 80), (256, 256, 8, 80), (128, 128, 16, 160), (128, 256, 8, 40),
+           (512, 64, 16, 80)]       # (round 4: 64 output channels -- the data-grad of the 64 -> 512 convolution -- on 128 x 64 product tiles)
     for K, N, H, W in yes:
         assert ops._wino_ok(K, N, 3, 3, True, H, W) and ops._wino_tile(H, W) == 4, (K, N, H, W)
     assert ops._wino_tile(4, 10) == 2 and ops._wino_ok(1024, 1024, 3, 3, True, 4, 10)          # L = 5: W = 2 L on the 4-row layers
     assert not ops._wino_ok(128, 128, 3, 3, True, 4, 10)                                        # (below F(2x2)'s 32 768 channel-pair floor)
-    for K, N, kh, same, H, W in [(64, 64, 3, True, 32, 160), (512, 64, 3, True, 16, 80), (512, 1024, 1, True, 8, 40), (512, 512, 3, False, 16, 80),
+    for K, N, kh, same, H, W in [(64, 64, 3, True, 32, 160), (512, 96, 3, True, 16, 80), (512, 1024, 1, True, 8, 40), (512, 512, 3, False, 16, 80),
                                  (512, 512, 3, True, 5, 80), (1, 64, 3, True, 32, 160), (512, 512, 2, True, 2, 40)]:
         assert not ops._wino_ok(K, N, kh, kh, same, H, W), (K, N, kh, same, H, W)
     # few-tile launches (every frequency plane is padded to 128 rows): the recognizer's 8 x 12 map at B = 3 has 18 tiles -- 36 x 128 rows

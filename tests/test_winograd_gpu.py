@@ -22,7 +22,7 @@ from tests import margins  # noqa: E402
 
 @pytest.fixture(params=[2, 4], ids=["F2x2", "F4x4"])
 def wino_everywhere(request):
-    """Every eligible shape (K % 32 == 0, N % 128 == 0, even H and W) through the Winograd path; F4x4: F(4x4, 3x3) wherever H and W
+    """Every eligible shape (K % 32 == 0, N % 64 == 0, even H and W) through the Winograd path; F4x4: F(4x4, 3x3) wherever H and W
     are multiples of 4 (the other shapes of the lists then run F(2x2, 3x3) again)."""
     from scrabble_gan_amd import ops
     old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.USE_WINOGRAD, ops.WINO_TILE, ops.WINO4_WGRAD_MIN_TILES, ops.WINO_ROW_GAIN)
@@ -52,7 +52,8 @@ def _close(got, ref, tol, name):
 # B, H, W, Cin, Cout: one tile per sample; tile counts below / not a multiple of the 128-row plane padding; odd batches; the
 # recognizer-like wide rows; Cin != Cout both ways (the data-grad runs when Cin % 128 == 0 too)
 SMALL = [(1, 2, 2, 32, 128), (1, 4, 4, 32, 128), (3, 4, 8, 128, 128), (3, 2, 4, 128, 128), (5, 4, 10, 96, 128), (2, 8, 40, 256, 128), (7, 6, 6, 32, 384), (2, 16, 80, 64, 128),
-         (33, 4, 20, 256, 256), (16, 4, 20, 128, 256)]
+         (33, 4, 20, 256, 256), (16, 4, 20, 128, 256),
+         (2, 8, 8, 128, 64), (3, 4, 12, 64, 64), (2, 16, 80, 512, 64), (5, 6, 10, 64, 192)]      # 64-wide product tiles (round 4): Cout % 128 == 64
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SMALL)

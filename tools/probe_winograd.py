@@ -20,6 +20,7 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ("R.conv4 b32", 32, 8, 40, 256, 256), ("R.conv5 b32", 32, 4, 40, 256, 512), ("R.conv6 b32", 32, 4, 40, 512, 512),
     ("D.B1.conv2 b384", 384, 32, 160, 64, 64), ("G.B3.conv b128", 128, 32, 160, 64, 64), ("R.conv2 b256", 256, 16, 80, 64, 128),
     ("D.B2.conv1 b32", 32, 16, 80, 64, 512), ("D.B1.conv2 b32", 32, 32, 160, 64, 64),
+    ("D.B2.conv1 b256", 256, 16, 80, 64, 512), ("D.B1.conv2 b256", 256, 32, 160, 64, 64), ("G.B3.conv b16", 16, 32, 160, 64, 64), ("R.conv2 b32", 32, 16, 80, 64, 128),
 ]
 
 
@@ -52,7 +53,7 @@ def main():
                "wgrad": lambda: ops.conv2d_bwd_weight(x, dy, dw, relu_in=True)}
         cells = []
         for d in ("fwd", "dgrad", "wgrad"):
-            if (d == "dgrad" and Ci % 128) or (d == "fwd" and Co % 128):
+            if (d == "dgrad" and Ci % ops.WINO_N_MULT) or (d == "fwd" and Co % ops.WINO_N_MULT):
                 cells.append("%21s" % "-")
                 continue
             ops.USE_WINOGRAD = False

@@ -18,6 +18,7 @@
 #define SG_MMA_BF16 256 // weight-grad: round the matrix-core operands to bf16 (fp32 accumulation); config c3
 
 #include <stdio.h>
+#include <stdlib.h>
 // Kernel launch + status.  hipGetLastError() returns the last error of ANY earlier runtime call of the thread -- also one the
 // host framework left behind (an event / stream query that was "not ready", a failed probe) -- so the slate is wiped right
 // before the launch, and the launch's own status is folded into a per-thread flag right after it: an entry point that queues
@@ -49,10 +50,16 @@ bool sg_deterministic();
 
 static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+// memory-bound kernels: cap the grid and grid-stride the rest.  4 096 workgroups (round 4; 2 048 before): beside a matrix-bound launch of
+// the other network's stream the sweeps get their CU slots one draining workgroup at a time, and a deeper queue of small workgroups keeps
+// more of them resident -- two-stream c2 step 138.6 -> 137.9 ms; caps of 1 024 / 512 / 256 cost 1 / 2.5 / 6 % (SG_HBM_GRID_CAP)
+static inline int sg_grid_cap() {
+  static const int cap = getenv("SG_HBM_GRID_CAP") ? atoi(getenv("SG_HBM_GRID_CAP")) : 4096;
+  return cap < 64 ? 64 : cap;
+}
 static inline int sg_grid_for(long work_items, int block) {
   long g = (work_items + block - 1) / block;
-  if (g > 2048) g = 2048;
+  if (g > sg_grid_cap()) g = sg_grid_cap();
   if (g < 1) g = 1;
   return (int)g;
 }

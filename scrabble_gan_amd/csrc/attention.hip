@@ -366,6 +366,7 @@ extern "C" int sg_attention_bwd(const float* theta, const float* phi, const floa
   const long waves = kblocks * kw;
   if (waves * zs < 2048 && (long)Nq * Nk >= (1L << 22)) zs = (int)((2048 + waves - 1) / waves);      // (large maps only)
   if (zs > 16) zs = 16;
+  if (sg_deterministic()) zs = 1;                       // (no query split: every dphi / dg row has one writer, plain stores)
   int q_chunk = sg_cdiv(sg_cdiv(Nq, zs), AT_QT) * AT_QT;        // whole LDS tiles per z slice
   zs = sg_cdiv(Nq, q_chunk);
   if (zs > 1) {

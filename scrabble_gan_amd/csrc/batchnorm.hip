@@ -238,7 +238,8 @@ extern "C" int sg_bn_bwd_reduce(const float* dy, const float* y, const float* x,
                                 float* dbeta_c, int B, int HW, int C, float eps, int relu, void* stream) {
   if (!dy || !x || !mean || !var || !gamma || !dgamma || !dbeta || !chan || !chan_ok(C) || (relu && !y)) return SG_ERR_ARG;
   long r = ((long)HW * B + 511) / 512;                  // ~512 workgroups; <= HW / 16 float atomics per [b, c] address
-  const int rpb = (int)(r < 16 ? 16 : (r > 512 ? 512 : r));
+  int rpb = (int)(r < 16 ? 16 : (r > 512 ? 512 : r));
+  if (sg_deterministic()) rpb = HW;                     // one workgroup per sample: ONE adder per [b, c] address (onto the caller's zeros), fixed order
   SG_KERNEL(k_bn_bwd_reduce, dim3(sg_cdiv(HW, rpb), B), dim3(256), 0, (hipStream_t)stream, dy, y, x, mean, var, dgamma,
                      dbeta, HW, C, eps, relu, rpb);
   SG_KERNEL(k_bn_bwd_chan, dim3(sg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dgamma, dbeta, gamma, gstride, B, C, chan,

@@ -357,7 +357,7 @@ extern "C" int sg_scale(const float* a, const float* s, float* out, long n, void
 
 extern "C" int sg_dot_accum(const float* a, const float* b, float* out, long n, void* stream) {
   if (!a || !b || !out || (n & 3)) return SG_ERR_ARG;
-  SG_KERNEL(k_dot, dim3(sg_grid_for(n / 4, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+  SG_KERNEL(k_dot, dim3(sg_deterministic() ? 1 : sg_grid_for(n / 4, 256 * 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);      // (deterministic: one adder)
   return sg_launch_status();
 }
 

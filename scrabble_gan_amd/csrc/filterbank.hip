@@ -63,6 +63,42 @@ __global__ __launch_bounds__(256) void k_filterbank_bwd_dz(const int* y, const f
               red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// The same sums with ONE adder per dz[b, k] (deterministic mode): one workgroup per sample walks its L characters and the 8 column
+// tiles in a fixed order, each thread keeps its 32 partial sums in registers, one tree at the end.
+__global__ __launch_bounds__(256) void k_filterbank_bwd_dz_det(const int* y, const float* table, const float* dseed, float* dz, int L, int vocab) {
+  __shared__ float red[4][FB_K];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W4 = 4 * L;
+  const size_t rs = (size_t)W4 * 512;
+  float acc[FB_K];
+#pragma unroll
+  for (int k = 0; k < FB_K; ++k) acc[k] = 0.f;
+  for (int l = 0; l < L; ++l) {
+    int cls = y[b * L + l];
+    cls = cls < 0 ? 0 : (cls >= vocab ? vocab - 1 : cls);
+    for (int jt = 0; jt < FB_J / 4 / 256; ++jt) {
+      const int j = 4 * (jt * 256 + threadIdx.x);
+      const int pw = j >> 11, q = (j & 2047) >> 2;
+      const size_t base = ((size_t)b * 4 * W4 + 4 * l + pw) * 512 + q;
+      const float4 d = make_float4(dseed[base], dseed[base + rs], dseed[base + 2 * rs], dseed[base + 3 * rs]);
+      const float* e = table + (size_t)cls * FB_K * FB_J + j;
+#pragma unroll 8
+      for (int k = 0; k < FB_K; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(e + (size_t)k * FB_J);
+        acc[k] += v.x * d.x + v.y * d.y + v.z * d.z + v.w * d.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < FB_K; ++k) {
+    const float s = sg_wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < FB_K) dz[(size_t)b * 128 + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // dE[c,k,j] += sum over the (b,l) with y[b,l] == c of z0[b,k]*dseed[...]
 // One workgroup per (column tile, class): it scans the B*L labels (wave ballots, ascending order, so the sum order is
 // fixed), keeps the 32 x 4 partial sums of its columns in registers and adds them to the table gradient ONCE, with
@@ -124,7 +160,8 @@ extern "C" int sg_filterbank_fwd(const float* z, const int* y, const float* tabl
 extern "C" int sg_filterbank_bwd(const float* z, const int* y, const float* table, const float* dseed, float* dtable, float* dz,
                                  int B, int L, int vocab, void* stream) {
   if (!z || !y || !table || !dseed || !dtable || !dz || B < 1 || L < 1) return SG_ERR_ARG;
-  SG_KERNEL(k_filterbank_bwd_dz, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, y, table, dseed, dz, L, vocab);
+  if (sg_deterministic()) SG_KERNEL(k_filterbank_bwd_dz_det, dim3(B), dim3(256), 0, (hipStream_t)stream, y, table, dseed, dz, L, vocab);
+  else SG_KERNEL(k_filterbank_bwd_dz, dim3(FB_J / 4 / 256, B * L), dim3(256), 0, (hipStream_t)stream, y, table, dseed, dz, L, vocab);
   SG_KERNEL(k_filterbank_bwd_table, dim3(FB_J / 4 / 256, vocab), dim3(256), 0, (hipStream_t)stream, z, y, dseed, dtable, B * L, L, vocab);
   return sg_launch_status();
 }

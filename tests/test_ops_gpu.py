@@ -413,3 +413,25 @@ def test_launch_status_keeps_an_earlier_failure(dev):
     assert out.sum().item() == 16.0
     with pytest.raises(TypeError):                      # arity is checked on the host before anything reaches the GPU
         _lib.call("sg_add", scratch.data_ptr(), scratch.data_ptr(), scratch.data_ptr(), 8)
+
+
+def test_one_adder_variants_of_deterministic_mode_vs_oracle(dev):
+    """`sg_set_deterministic(1)` switches the float-atomic reductions outside the convolutions to one-adder forms (round 4): BatchNorm's
+    backward reduce with one workgroup per sample, the filter bank's dz kernel with one workgroup per sample (a different kernel:
+    k_filterbank_bwd_dz_det), the attention key sweep without the query split, the sigma dot product on one workgroup.  The same
+    oracle checks as in default mode, run with the switch on."""
+    from scrabble_gan_amd import ops
+    ops.set_deterministic(True)
+    try:
+        test_filterbank(dev, torch.Generator().manual_seed(1234))
+        for per_sample, relu, C in ((True, True, 64), (False, False, 512)):
+            test_batchnorm(dev, torch.Generator().manual_seed(1234), per_sample, relu, C)
+        for B, Nq, Nk in ((2, 640, 160), (3, 200, 300), (2, 1280, 320), (1, 5120, 1280)):      # (the last two would split the query range)
+            test_attention(dev, torch.Generator().manual_seed(1234), B, Nq, Nk)
+        a, b = torch.randn(4096, device=dev), torch.randn(4096, device=dev)
+        out = torch.zeros(1, device=dev)
+        from scrabble_gan_amd._lib import call
+        call("sg_dot_accum", a.data_ptr(), b.data_ptr(), out.data_ptr(), 4096, ops._stream())
+        close(out, (a.double() * b.double()).sum().reshape(1), tol=1e-5, name="dot (one workgroup)")
+    finally:
+        ops.set_deterministic(False)

@@ -434,3 +434,40 @@ def test_network_and_side_streams_do_not_change_the_step(dev, conv_dtype):
     except OSError:
         pass
     assert not bad, "\n".join(bad[:10])
+
+
+def test_deterministic_mode_makes_the_whole_step_bitwise_reproducible(dev):
+    """`configure(deterministic=True)` (-> sg_set_deterministic): every float-atomic accumulation of the step has ONE adder per address --
+    no reduction splits and one pixel chunk in the convolutions (rounds 2-3), and since round 4 also BatchNorm's per-sample dgamma /
+    dbeta partials (one workgroup per sample), the filter bank's dz (one workgroup per sample, fixed loop order), the attention key
+    sweep (no query split) and the sigma dot product (one workgroup); the Winograd weight-grad gives way to the direct kernel's
+    single-chunk form and the second stream is off.  Two runs of the same step from the same state must then agree BITWISE in all 16
+    scalars and in every gradient tensor of all four networks (the mode used to cover the convolutions only).
+    (Spectral norm's power iteration -- kernel_reg = 'applied' only -- still adds through float atomics and is not part of this step.)"""
+    from tests import step_fixture as F
+    from scrabble_gan_amd import data_utils as DU, net_architecture as NA, net_loss, ops, optimizers
+    pb = F.make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=70.0)
+    B = pb["B"]
+    runs = []
+    NA.configure(device=dev, seed=9, deterministic=True)
+    try:
+        assert ops.DETERMINISTIC and not ops.net_stream_enabled(3 * B)
+        for _ in range(2):
+            NA._model_counter[0] = 0
+            models, gan, nlg = F.load_models(NA, pb, dev)
+            G, D, R, S = (models[n] for n in ("G", "D", "R", "S"))
+            opts = [optimizers.Adam(2e-4, 0.0, 0.999) for _ in range(4)]
+            out = DU.train_step(0, 0, 1, pb["images"].float().numpy(), pb["labels"].numpy().astype(np.int32), D, R, S, gan, opts[0],
+                                opts[1], opts[2], opts[3], pb["style"].float().numpy(), B, 128, net_loss.hinge, 1, 1, None, 10, "",
+                                fake_labels=pb["fake"].numpy().astype(np.int32), nl=nlg, verbose=False)
+            runs.append((np.array(out, np.float64), {n: m.store.grad.clone() for n, m in models.items()},
+                         {n: m.store.flat.clone() if hasattr(m.store, "flat") else None for n, m in models.items()}))
+    finally:
+        NA.configure(deterministic=False)
+    (sa, ga, wa), (sb, gb, wb) = runs
+    assert np.array_equal(sa, sb), (sa, sb)
+    for n in ("D", "R", "S", "G"):
+        diff = (ga[n] - gb[n]).abs().max().item()
+        assert torch.equal(ga[n], gb[n]), "%s: gradients of two deterministic runs differ by up to %.3e" % (n, diff)
+        if wa[n] is not None:
+            assert torch.equal(wa[n], wb[n]), "%s: post-Adam weights differ" % n

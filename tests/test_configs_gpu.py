@@ -136,8 +136,9 @@ def test_c5_fp8_step_at_the_bs64_shard_tracks_fp32(NA, dev):
     profiles/r04_diag_c5.txt.  The fp8 launches themselves are unbiased: gain 0.9985 forward / data-grad, 0.996 weight-grad per
     launch, profiles/r04_diag_fp8_bias.txt; no underflow of the gradient operands, profiles/r04_diag_c5_quant.txt).
 
-    Two steps: (1) gradient balancing OFF -- no forward-side scalar in the gradient: |g(fp8)| / |g(fp32)| within +-3 % and cosine >
-    0.95 for every network (measured G 0.983 / 0.980, D 0.986 / 0.997, S 1.000 / 0.994, R 1.000 / 1.000);  (2) balancing ON (c5
+    Two steps: (1) gradient balancing OFF -- no forward-side scalar in the gradient: cosine > 0.95 and |g(fp8)| / |g(fp32)| in a band around
+    its EXPECTED value for every network (measured over four runs: G 0.978-0.983 / cos 0.980, D 0.987 / 0.997, S 1.000 / 0.994, R 1.000 /
+    1.000; bands G [0.965, 1.0], D [0.97, 1.01], S and R +-1 % -- G's 2 % below 1 is the rounding bias of ten fp8 launches, see below);  (2) balancing ON (c5
     itself): cosines D / S > 0.98 (measured 0.997 / 0.993), R > 0.999, G > 0.9 (measured 0.969; 0.75 was the bar of round 3), and G's norm ratio within 5 % of the interval between 1 and the
     ratio of the two runs' balancing factors std(g_loss) / std(r_fake) (G's gradient = g_loss part + factor x recognizer part).
     Scalars within 0.2 * max(1, |fp32|), fake images within 0.2 (z x 30 amplifies G's own fp8 rounding: measured 0.156).
@@ -168,10 +169,15 @@ def test_c5_fp8_step_at_the_bs64_shard_tracks_fp32(NA, dev):
         assert (x8 - x32).abs().max().item() <= 0.2
         for n in ("D", "R", "S", "G"):
             if not balance:
-                assert cos[n] > 0.95 and abs(nrm[n] - 1.0) <= 0.03, "%s (balancing off): cosine %.4f, norm ratio %.4f" % (n, cos[n], nrm[n])
+                # Expected value, not only a band: round-to-nearest onto a 3-bit (e4m3) / 2-bit (e5m2) mantissa shrinks bell-shaped data by
+                # 0.07 % / 0.3 % per operand (more mass in the lower half of every quantisation cell; profiles/r04_diag_c5_quant.txt), i.e.
+                # 0.14-0.4 % per launch (r04_diag_fp8_bias.txt) and ~2 % over the ~10 fp8 launches a gradient of G crosses, ~1.3 % for D;
+                # S and R (bf16) sit at 1.000.  Bands: G 0.98 -1.5 / +2 %, D 0.987 -1.7 / +2.3 %, S and R +-1 % -- all inside +-3.5 % of 1.
+                lo, hi = {"G": (0.965, 1.0), "D": (0.97, 1.01), "S": (0.99, 1.01), "R": (0.99, 1.01)}[n]
+                assert cos[n] > 0.95 and lo <= nrm[n] <= hi, "%s (balancing off): cosine %.4f, norm ratio %.4f outside [%.3f, %.3f]" % (n, cos[n], nrm[n], lo, hi)
             else:
                 assert cos[n] > {"G": 0.9, "D": 0.98, "S": 0.98, "R": 0.999}[n], "%s: cosine %.4f" % (n, cos[n])
         if balance:
             lo, hi = min(1.0, rho) - 0.05, max(1.0, rho) + 0.05
             assert lo <= nrm["G"] <= hi, "G: norm ratio %.4f outside [%.3f, %.3f] (balancing-factor ratio %.4f)" % (nrm["G"], lo, hi, rho)
-            assert abs(nrm["D"] - 1.0) <= 0.03 and abs(nrm["S"] - 1.0) <= 0.03 and abs(nrm["R"] - 1.0) <= 0.03, nrm
+            assert 0.97 <= nrm["D"] <= 1.01 and abs(nrm["S"] - 1.0) <= 0.02 and abs(nrm["R"] - 1.0) <= 0.01, nrm

@@ -409,10 +409,12 @@ def test_network_and_side_streams_do_not_change_the_step(dev, conv_dtype):
     # address here, what is left is float-atomic BatchNorm / filter-bank / attention partial sums: 1e-5 of a scalar, 3e-4 of a
     # network's largest gradient.  bf16 / fp8 -- the reduction-split tiles of the convolutions meet through float atomics in a
     # run-dependent order and every result is re-quantised for the next launch, so two SINGLE-stream runs already differ at the
-    # operand precision (measured: scalars 1e-4 / 3e-2 relative, profiles/r04_streams_vs_single_{bf16,fp8}.txt): 2e-3 / 5e-2 of a
-    # scalar, 2e-2 / 1e-1 of the largest gradient.  A missing event or join reads operand copies that are not written yet --
+    # operand precision (measured: scalars 2e-3 / 3e-2 relative, profiles/r04_streams_vs_single_{bf16,fp8}.txt): 1e-2 / 1e-1 of a
+    # scalar, 8e-2 / 4e-1 of the largest gradient.  A missing event or join reads operand copies that are not written yet --
     # errors of the order of the values themselves -- and stays far outside either.
-    s_floor, g_floor = {"f32": (1e-5, 3e-4), "bf16": (2e-3, 2e-2), "fp8": (5e-2, 1e-1)}[conv_dtype]
+    # (bf16 / fp8 floors sit above the LARGEST single-stream run-to-run differences seen -- bf16: scalars 2e-3, G.filter_bank 3.5 % of the
+    #  network's largest gradient; fp8: 3e-2, D.B4.conv2.b 19 % -- so that the verdict never hangs on one noisy noise estimate)
+    s_floor, g_floor = {"f32": (1e-5, 3e-4), "bf16": (1e-2, 8e-2), "fp8": (1e-1, 4e-1)}[conv_dtype]
     lines, bad = [], []
     for i in range(16):
         lines.append("scalar %2d: streams %.6e  single %.6e  single' %.6e" % (i, sa[i], sb[i], sc[i]))

@@ -30,6 +30,11 @@ extern "C" {
 #define SG_ACCUM 2     /* out += result                                                          */
 #define SG_RELU_OUT 4  /* max(.,0) applied to the result                                          */
 #define SG_TANH_OUT 8  /* tanh applied to the result (Cout == 1 path)                             */
+#define SG_UPS2_IN 64   /* sg_conv2d_bwd_data_wino / sg_conv2d_bwd_weight_wino with tile = 4 only: the gradient operand dy is given at HALF
+                         * resolution [B,H/2,W/2,Cout] and stands for 0.25 * upsample2x2(dy) -- the backward of tf.nn.pool(AVG) (resnet_ops.py:105-106)
+                         * folded into the gradient transforms; H, W stay the convolution's (full) size */
+#define SG_POOL2_OUT 16 /* sg_conv2d_fwd_wino / sg_wino_output with tile = 4 only: y [B,H/2,W/2,N] (+)= avg_pool2x2(conv + bias) -- the
+                         * conv2 -> tf.nn.pool(AVG) pair of a ResNetBlockDown (resnet_ops.py:102-106) without the full-resolution tensor */
 #define SG_MMA_BF16 256 /* sg_conv2d_bwd_weight: bf16 matrix-core operands, fp32 accumulation (config c3)  */
 
 /* ---- convolutions: layers.Conv2D stride 1 (bigacgan/resnet_ops.py:65,98,103,109;
@@ -93,6 +98,7 @@ long sg_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
 long sg_wino_plane_rows(int B, int H, int W, int tile);
 int sg_wino_filter(const float* w_nk, float* u, int N, int K, int flip, int tile, void* stream);
 int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, void* stream);
+int sg_wino_input_ups(const float* x_half, float* V, int B, int H, int W, int C, int tile, void* stream);   /* V of 0.25 * upsample2x2(x_half [B,H/2,W/2,C]); tile = 4 */
 int sg_wino_gemm(const float* V, const float* u, float* Mt, int B, int H, int W, int K, int N, int tile, void* stream);
 int sg_wino_output(const float* Mt, float* y, const float* bias, const float* bias2, const float* mask,
                    int B, int H, int W, int N, int flags, int tile, void* stream);
@@ -112,6 +118,8 @@ int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* ma
 long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int tile);
 int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch,
                        int B, int H, int W, int N, int tile, void* stream);
+int sg_wino_grad_input_ups(const float* dy_half, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H, int W,
+                           int N, int tile, void* stream);      /* the same for dy = 0.25 * upsample2x2(dy_half [B,H/2,W/2,N]); tile = 4 */
 int sg_wino_wgrad_gemm(const float* V, const float* Qt, float* dU, int B, int H, int W, int K, int N, int tile, long v_plane_rows, void* stream);
 int sg_wino_filter_grad(const float* dU, float* dw, int K, int N, int tile, void* stream);
 int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float* dw, float* db, const float* sample_scale,

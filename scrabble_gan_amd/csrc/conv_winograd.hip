@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void k_w43_filter(const float* __restrict__ in
   }
 }
 
-template <bool RELU, typename VT>
+// UPS (round 4): x is the HALF-resolution tensor [B, H/2, W/2, C] and the patch is taken from 0.25 * upsample2x2(x) -- the backward of a 2x2
+// AVG pool folded into the transform of the gradient it produces (16 loads per tile instead of 36, no full-resolution gradient in HBM)
+template <bool RELU, typename VT, bool UPS = false>
 __global__ __launch_bounds__(256) void k_w43_in(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, long T, long Tp) {
   constexpr int VW = sizeof(VT) / 4;
   const int CV = C / VW, H4 = H >> 2, W4 = W >> 2;
@@ -316,7 +318,10 @@ __global__ __launch_bounds__(256) void k_w43_in(const float* __restrict__ x, flo
       for (int a = 0; a < 6; ++a) {
         const int iy = 4 * ty - 1 + a;
         VT v = zerov<VT>();
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ldv<VT>(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          if constexpr (UPS) v = ldv<VT>(x + ((size_t)(b * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * C + c) * 0.25f;
+          else v = ldv<VT>(x + ((size_t)(b * H + iy) * W + ix) * C + c);
+        }
         d[a] = RELU ? reluv<VT>(v) : v;
       }
       w43_bt(d[0], d[1], d[2], d[3], d[4], d[5], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void k_w43_in(const float* __restrict__ x, flo
   }
 }
 
-template <typename VT>
+template <typename VT, bool POOL = false>
 __global__ __launch_bounds__(256) void k_w43_out(const float* __restrict__ Mt, float* __restrict__ y, const float* __restrict__ bias,
                                                  const float* __restrict__ bias2, const float* __restrict__ mask, int H, int W, int N, long T,
                                                  long Tp, int flags) {
@@ -360,29 +365,48 @@ __global__ __launch_bounds__(256) void k_w43_out(const float* __restrict__ Mt, f
     VT bs = zerov<VT>();
     if (bias) bs += ldv<VT>(bias + n);
     if (bias2) bs += ldv<VT>(bias2 + n);
+    if constexpr (POOL) {
+      // SG_POOL2_OUT: the 4 x 4 tile's 2 x 2 means (+ bias: a mean of conv + b is the mean of conv, + b) go to the pooled tensor
+      // [B, H/2, W/2, N]; no mask / output ReLU in this form
+      const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      VT o[4];
-      w43_at(q[i][0], q[i][1], q[i][2], q[i][3], q[i][4], q[i][5], o[0], o[1], o[2], o[3]);
+      for (int pi = 0; pi < 2; ++pi) {
+        VT o0[4], o1[4];
+        w43_at(q[2 * pi][0], q[2 * pi][1], q[2 * pi][2], q[2 * pi][3], q[2 * pi][4], q[2 * pi][5], o0[0], o0[1], o0[2], o0[3]);
+        w43_at(q[2 * pi + 1][0], q[2 * pi + 1][1], q[2 * pi + 1][2], q[2 * pi + 1][3], q[2 * pi + 1][4], q[2 * pi + 1][5], o1[0], o1[1], o1[2], o1[3]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        VT v = o[j] + bs;
-        const size_t idx = ((size_t)(b * H + 4 * ty + i) * W + 4 * tx + j) * N + n;
-        if (mask) {
-          const VT k = ldv<VT>(mask + idx);
-#pragma unroll
-          for (int e = 0; e < VW; ++e)
-            if (k[e] <= 0.f) v[e] = 0.f;
+        for (int pj = 0; pj < 2; ++pj) {
+          VT v = ((o0[2 * pj] + o0[2 * pj + 1]) + (o1[2 * pj] + o1[2 * pj + 1])) * 0.25f + bs;
+          const size_t idx = ((size_t)(b * Hp + 2 * ty + pi) * Wp + 2 * tx + pj) * N + n;
+          if (accum) v += ldv<VT>(y + idx);
+          stv<VT>(y + idx, v);
         }
-        if (accum) v += ldv<VT>(y + idx);
-        if (relu_out) v = reluv<VT>(v);
-        stv<VT>(y + idx, v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        VT o[4];
+        w43_at(q[i][0], q[i][1], q[i][2], q[i][3], q[i][4], q[i][5], o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          VT v = o[j] + bs;
+          const size_t idx = ((size_t)(b * H + 4 * ty + i) * W + 4 * tx + j) * N + n;
+          if (mask) {
+            const VT k = ldv<VT>(mask + idx);
+#pragma unroll
+            for (int e = 0; e < VW; ++e)
+              if (k[e] <= 0.f) v[e] = 0.f;
+          }
+          if (accum) v += ldv<VT>(y + idx);
+          if (relu_out) v = reluv<VT>(v);
+          stv<VT>(y + idx, v);
+        }
       }
     }
   }
 }
 
-template <typename VT>
+template <typename VT, bool UPS = false>
 __global__ __launch_bounds__(256) void k_w43_dy(const float* __restrict__ dy, float* __restrict__ Qt, const float* __restrict__ sample_scale,
                                                 float* __restrict__ db_in, float* __restrict__ db_part, int H, int W, int N, long T, long Tp) {
   float* const db = db_in ? (db_part ? db_part + (size_t)(blockIdx.x % WINO_DB_PARTS) * N : db_in) : nullptr;
@@ -408,7 +432,8 @@ __global__ __launch_bounds__(256) void k_w43_dy(const float* __restrict__ dy, fl
       VT d[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        d[a] = ldv<VT>(dy + ((size_t)(b * H + 4 * ty + a) * W + 4 * tx + j) * N + n) * sc;
+        if constexpr (UPS) d[a] = ldv<VT>(dy + ((size_t)(b * (H >> 1) + 2 * ty + (a >> 1)) * (W >> 1) + 2 * tx + (j >> 1)) * N + n) * (0.25f * sc);
+        else d[a] = ldv<VT>(dy + ((size_t)(b * H + 4 * ty + a) * W + 4 * tx + j) * N + n) * sc;
         s4 += d[a];
       }
       w43_a(d[0], d[1], d[2], d[3], rr[0][j], rr[1][j], rr[2][j], rr[3][j], rr[4][j], rr[5][j]);
@@ -501,9 +526,24 @@ extern "C" int sg_wino_filter(const float* w_nk, float* u, int N, int K, int fli
 }
 
 // ---- the three steps as separate entry points (the host times them apart: two HBM-bound sweeps around one matrix-bound launch)
+static int wino_input_impl(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, int ups, void* stream);
 extern "C" int sg_wino_input(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, void* stream) {
+  return wino_input_impl(x, V, B, H, W, C, relu, tile, 0, stream);
+}
+// x_half [B, H/2, W/2, C] -> V of 0.25 * upsample2x2(x_half) (tile = 4 only; no operand ReLU): the input transform of a data-grad whose
+// gradient operand is the backward of a 2x2 AVG pool (resnet_ops.py:105-106), without the full-resolution gradient
+extern "C" int sg_wino_input_ups(const float* x_half, float* V, int B, int H, int W, int C, int tile, void* stream) {
+  if (tile != 4) return SG_ERR_UNSUPPORTED;
+  return wino_input_impl(x_half, V, B, H, W, C, 0, tile, 1, stream);
+}
+static int wino_input_impl(const float* x, float* V, int B, int H, int W, int C, int relu, int tile, int ups, void* stream) {
   if (!x || !V) return SG_ERR_ARG;
   if (!wino_shape_ok(B, H, W, C, 64, tile)) return SG_ERR_UNSUPPORTED;
+  if (ups) {
+    const long Tu = wino_tiles(B, H, W, 4);
+    SG_KERNEL((k_w43_in<false, v4f, true>), dim3(sg_grid_for(Tu * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, V, H, W, C, Tu, wino_tp(Tu));
+    return sg_launch_status();
+  }
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(sg_grid_for(T * (C / 4), 256)), block(256);
@@ -547,8 +587,13 @@ extern "C" int sg_wino_output(const float* Mt, float* y, const float* bias, cons
                               int flags, int tile, void* stream) {
   if (!Mt || !y) return SG_ERR_ARG;
   if (!wino_shape_ok(B, H, W, 32, N, tile) || (flags & (SG_TANH_OUT | SG_RELU_IN))) return SG_ERR_UNSUPPORTED;
+  if ((flags & SG_POOL2_OUT) && (tile != 4 || mask || (flags & SG_RELU_OUT))) return SG_ERR_UNSUPPORTED;
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
   const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
+  if (flags & SG_POOL2_OUT) {
+    SG_KERNEL((k_w43_out<v4f, true>), grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
+    return sg_launch_status();
+  }
   if (tile == 2) SG_KERNEL(k_wino_out, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
   else if (wino_vec() == 2) SG_KERNEL(k_w43_out<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
   else SG_KERNEL(k_w43_out<v4f>, grid, block, 0, (hipStream_t)stream, Mt, y, bias, bias2, mask, H, W, N, T, Tp, flags);
@@ -564,11 +609,11 @@ static int wino_conv(const float* a, const float* u, const float* bias, const fl
   const long Tp = wino_tp(wino_tiles(B, H, W, tile));
   float* V = reinterpret_cast<float*>(workspace);
   float* Mt = V + (size_t)wino_planes(tile) * Tp * K;
-  int rc = sg_wino_input(a, V, B, H, W, K, (flags & SG_RELU_IN) != 0, tile, s);
+  int rc = wino_input_impl(a, V, B, H, W, K, (flags & SG_RELU_IN) != 0, tile, (flags & SG_UPS2_IN) != 0, s);
   if (rc != SG_OK) return rc;
   rc = sg_wino_gemm(V, u, Mt, B, H, W, K, N, tile, s);
   if (rc != SG_OK) return rc;
-  return sg_wino_output(Mt, out, bias, bias2, mask, B, H, W, N, flags & ~SG_RELU_IN, tile, s);
+  return sg_wino_output(Mt, out, bias, bias2, mask, B, H, W, N, flags & ~(SG_RELU_IN | SG_UPS2_IN), tile, s);
 }
 
 extern "C" int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const float* bias, const float* bias2, float* y, int B, int H, int W,
@@ -578,7 +623,8 @@ extern "C" int sg_conv2d_fwd_wino(const float* x, const float* u_fwd, const floa
 
 extern "C" int sg_conv2d_bwd_data_wino(const float* dy, const float* u_bwd, const float* mask, float* dx, int B, int H, int W, int Cin,
                                        int Cout, int flags, int tile, void* workspace, long workspace_bytes, void* stream) {
-  if (flags & (SG_RELU_IN | SG_RELU_OUT)) return SG_ERR_ARG;
+  if (flags & (SG_RELU_IN | SG_RELU_OUT | SG_POOL2_OUT)) return SG_ERR_ARG;
+  if ((flags & SG_UPS2_IN) && tile != 4) return SG_ERR_UNSUPPORTED;
   return wino_conv(dy, u_bwd, nullptr, nullptr, mask, dx, B, H, W, Cout, Cin, flags, tile, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -589,8 +635,20 @@ extern "C" long sg_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
   return (long)sizeof(float) * (wino_planes(tile) * (Tp * ((long)Cin + Cout) + (long)Cin * Cout) + (long)WINO_DB_PARTS * Cout);
 }
 
+static int wino_grad_input_impl(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H, int W,
+                                int N, int tile, int ups, void* stream);
 extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H, int W,
                                   int N, int tile, void* stream) {
+  return wino_grad_input_impl(dy, Qt, sample_scale, db, db_scratch, B, H, W, N, tile, 0, stream);
+}
+// dy_half [B, H/2, W/2, N]: the gradient transform (and bias gradient) of 0.25 * upsample2x2(dy_half); tile = 4 only
+extern "C" int sg_wino_grad_input_ups(const float* dy_half, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H,
+                                      int W, int N, int tile, void* stream) {
+  if (tile != 4) return SG_ERR_UNSUPPORTED;
+  return wino_grad_input_impl(dy_half, Qt, sample_scale, db, db_scratch, B, H, W, N, tile, 1, stream);
+}
+static int wino_grad_input_impl(const float* dy, float* Qt, const float* sample_scale, float* db, float* db_scratch, int B, int H, int W,
+                                int N, int tile, int ups, void* stream) {
   if (!dy || !Qt) return SG_ERR_ARG;
   if (!wino_geom_ok(B, H, W, tile) || (N & 3) || N <= 0) return SG_ERR_UNSUPPORTED;
   const long T = wino_tiles(B, H, W, tile), Tp = wino_tp(T);
@@ -598,7 +656,8 @@ extern "C" int sg_wino_grad_input(const float* dy, float* Qt, const float* sampl
   const dim3 grid(sg_grid_for(T * (N / 4), 256)), block(256);
   float* part = db ? db_scratch : nullptr;       // (db_scratch: WINO_DB_PARTS x N floats; null -> every block adds into db itself)
   if (part && hipMemsetAsync(part, 0, sizeof(float) * (size_t)WINO_DB_PARTS * N, s) != hipSuccess) return SG_ERR_LAUNCH;
-  if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
+  if (ups) SG_KERNEL((k_w43_dy<v4f, true>), grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
+  else if (tile == 2) SG_KERNEL(k_wino_dy, grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
   else if (wino_vec() == 2) SG_KERNEL(k_w43_dy<v2f>, dim3(sg_grid_for(T * (N / 2), 256)), block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
   else SG_KERNEL(k_w43_dy<v4f>, grid, block, 0, s, dy, Qt, sample_scale, db, part, H, W, N, T, Tp);
   if (part) SG_KERNEL(k_wino_db_finish, dim3(sg_cdiv(N, 256)), dim3(256), 0, s, part, db, N);
@@ -647,7 +706,8 @@ extern "C" int sg_conv2d_bwd_weight_wino(const float* x, const float* dy, float*
   float* dU = Qt + (size_t)F * Tp * Cout;
   int rc = sg_wino_input(x, V, B, H, W, Cin, (flags & SG_RELU_IN) != 0, tile, stream);
   if (rc != SG_OK) return rc;
-  rc = sg_wino_grad_input(dy, Qt, sample_scale, db, dU + (size_t)F * Cin * Cout, B, H, W, Cout, tile, stream);
+  if ((flags & SG_UPS2_IN) && tile != 4) return SG_ERR_UNSUPPORTED;
+  rc = wino_grad_input_impl(dy, Qt, sample_scale, db, dU + (size_t)F * Cin * Cout, B, H, W, Cout, tile, (flags & SG_UPS2_IN) != 0, stream);
   if (rc != SG_OK) return rc;
   rc = sg_wino_wgrad_gemm(V, Qt, dU, B, H, W, Cin, Cout, tile, 0, stream);
   if (rc != SG_OK) return rc;

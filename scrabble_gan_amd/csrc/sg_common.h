@@ -15,6 +15,8 @@
 #define SG_ACCUM 2      // out += result instead of out = result
 #define SG_RELU_OUT 4   // apply max(.,0) to the result
 #define SG_TANH_OUT 8   // apply tanh to the result (thin Cout=1 path only)
+#define SG_UPS2_IN 64   // Winograd F(4x4) data-grad / weight-grad: the gradient operand is given at HALF resolution, dy = 0.25 * upsample2x2(dy_half)
+#define SG_POOL2_OUT 16 // Winograd F(4x4) forward only: the result is avg_pool2x2(conv + bias), written / accumulated as [B, H/2, W/2, N]
 #define SG_MMA_BF16 256 // weight-grad: round the matrix-core operands to bf16 (fp32 accumulation); config c3
 
 #include <stdio.h>

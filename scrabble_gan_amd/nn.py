@@ -215,9 +215,8 @@ def block_down_fwd(x, S: ParamStore, pre: str, is_last: bool):
         out = ops.conv2d_fwd(x, p[pre + ".short.w"], p[pre + ".short.b"])                     # :109-111
         ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True, out=out, accum=True)   # :102-104,114
     elif POOL_FIRST_SHORTCUT and x.shape[-1] % 4 == 0:
-        c2 = ops.conv2d_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)
         xp = ops.avgpool2_add_fwd(x)                                                          # pooled block input
-        out = ops.avgpool2_add_fwd(c2)                                                        # :105-106
+        out = ops.conv2d_avgpool_fwd(c1, p[pre + ".conv2.w"], p[pre + ".conv2.b"], relu_in=True)   # :102-106 (pooled in the conv's epilogue where it can be)
         ops.conv2d_fwd(xp, p[pre + ".short.w"], p[pre + ".short.b"], out=out, accum=True, want16=True)     # :109-114, pooled first
         # (want16: in bf16 mode the launch that completes the block's output also writes its bf16 twin -- the next block's conv
         #  operand -- instead of a conversion sweep over the finished tensor)
@@ -242,21 +241,30 @@ def block_down_bwd(ctx, dout, S: ParamStore, pre: str, is_last: bool, want_dx: b
     if want_dw and pooled_short and not one_join:     # the shortcut saw avg_pool(x): its weight / bias gradients come from the pooled grid
         with ops.side_stream(xp, dout, wscale):
             ops.conv2d_bwd_weight(xp, dout, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
-    if is_last:
+    cin, cout = x.shape[-1], c1.shape[-1]
+    fold = (pooled_short and not is_last and not one_join and not ops.side_enabled()
+            and ops.pooled_grad_foldable(x.shape[0], H, W, cout, cout, want_dw))
+    if fold:
+        # (round 4) conv2's two backward launches read the POOLED gradient: d_c2 = 0.25 * upsample(dout) is folded into their Winograd
+        # gradient transforms and never written (ops.conv2d_avgpool_bwd); conv2 is cout -> cout, its input c1 is also its ReLU mask
+        d_c1 = ops.conv2d_avgpool_bwd(c1, dout, p[pre + ".conv2.w"], c1, dw=g[pre + ".conv2.w"] if want_dw else None,
+                                      db=g[pre + ".conv2.b"] if want_dw else None, sample_scale=wscale, relu_in=True)
+        d_c2 = None
+    elif is_last:
         d_c2 = dout                  # gradient of conv2's output (and of the 1x1 output when it pools last)
     elif pooled_short:               # only conv2's launches read it: low-precision modes write their operand copies directly
         d_c2 = ops.avgpool2_bwd_operands(dout, wscale, want_dw)
     else:
         d_c2 = ops.avgpool2_bwd(dout)
-    if want_dw and not one_join:          # (weight gradients are leaves of the sweep: side stream, see ops.side_stream)
+    if want_dw and not one_join and not fold:          # (weight gradients are leaves of the sweep: side stream, see ops.side_stream)
         with ops.side_stream(c1, x, d_c2, wscale):
             ops.conv2d_bwd_weight(c1, d_c2, g[pre + ".conv2.w"], relu_in=True, db=g[pre + ".conv2.b"], sample_scale=wscale)
             if not pooled_short:
                 ops.conv2d_bwd_weight(x, d_c2, g[pre + ".short.w"], db=g[pre + ".short.b"], sample_scale=wscale)
     # (bf16 twin of d_c1 from the epilogue, unless both of its consumers -- conv1's weight-grad and data-grad -- read fp8 copies)
-    cin, cout = x.shape[-1], c1.shape[-1]
-    d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True),
-                               amax_scale=wscale)
+    if not fold:
+        d_c1 = ops.conv2d_bwd_data(d_c2, p[pre + ".conv2.w"], (H, W), mask=c1, want16=not ops._fp8_wgrad_ok(cin, cout, 3, 3, True),
+                                   amax_scale=wscale)
     if one_join:
         with ops.side_stream(x, c1, xp, dout, d_c2, d_c1, wscale):
             if pooled_short:

@@ -824,10 +824,14 @@ def _wino_workspace(nbytes: int, like: torch.Tensor) -> torch.Tensor:
     return buf
 
 
-def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flags: int, tag) -> None:
+def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flags: int, tag, ups: bool = False) -> None:
     """out [B,H,W,N] = conv3x3_same(a [B,H,W,K]) through input transform -> grouped products -> output transform (tag[0] = "wino_fwd":
-    forward of the filter w; "wino_dgrad": its data-grad)."""
+    forward of the filter w; "wino_dgrad": its data-grad).  ups (data-grad, F(4x4)): a is the half-resolution gradient [B,H/2,W/2,K] and
+    stands for 0.25 * upsample2x2(a) (UPS2_IN)."""
     B, H, W, _ = a.shape
+    if ups:
+        H, W = 2 * H, 2 * W
+        flags |= UPS2_IN
     tile = _wino_tile(H, W)
     P = (tile + 2) ** 2
     fwd = tag[0] == "wino_fwd"
@@ -863,7 +867,10 @@ def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
     with _hbm("wino_transform", a, flops=0.0) as _:
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * K
-        call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), tile, s)
+        if ups:
+            call("sg_wino_input_ups", _p(a), V, B, H, W, K, tile, s)
+        else:
+            call("sg_wino_input", _p(a), V, B, H, W, K, int(relu_in), tile, s)
     with _timed("igemm_wino", 2.0 * P * Tp * K * N, False, tag):        # (executed FLOPs: the grouped products, pad rows included)
         if PROFILER is not None and PROFILER.wants("igemm_wino"):
             PROFILER.nbytes["igemm_wino"] = PROFILER.nbytes.get("igemm_wino", 0.0) + 4.0 * P * (Tp * K + N * K + Tp * N)
@@ -871,7 +878,7 @@ def _wino_conv(a, w, out, bias, bias2, mask, K: int, N: int, relu_in: bool, flag
     with _hbm("wino_transform", out, mask, flops=0.0):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * N
-        call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags, tile, s)
+        call("sg_wino_output", Mt, _p(out), _p(bias), _p(bias2), _p(mask), B, H, W, N, flags & ~UPS2_IN, tile, s)
 
 
 def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W: int) -> bool:
@@ -884,12 +891,14 @@ def _wino_wgrad_ok(Cin: int, Cout: int, kh: int, kw: int, same: bool, H: int, W:
     return min(Cin, Cout) >= WINO_MIN_C[t] and Cin * Cout >= (min(WINO_MIN_KN[4], 4096) if t == 4 else WINO_MIN_KN[2])      # (F(4x4): 64 -> 64 included)
 
 
-def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
+def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool, ups: bool = False) -> None:
+    """ups (F(4x4) only): dy is the half-resolution gradient [B,H/2,W/2,Cout] standing for 0.25 * upsample2x2(dy)."""
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     tile = _wino_tile(H, W)
     if tile == 4 and B * (H // 4) * (W // 4) < WINO4_WGRAD_MIN_TILES:
         tile = 2
+    assert not ups or tile == 4
     P = (tile + 2) ** 2
     T = B * (H // tile) * (W // tile)
     Tp = -(-T // 128) * 128
@@ -904,14 +913,15 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
     if kept is not None:
         V, v_rows = kept
     elif PROFILER is None:
-        call("sg_conv2d_bwd_weight_wino", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, 1 if relu_in else 0, tile, V, nbytes, s)
+        call("sg_conv2d_bwd_weight_wino", _p(x), _p(dy), _p(dw), _p(db), _p(sample_scale), B, H, W, Cin, Cout, (1 if relu_in else 0) | (UPS2_IN if ups else 0),
+             tile, V, nbytes, s)
         return
     with _hbm("wino_transform", x if kept is None else None, dy):
         if PROFILER is not None and PROFILER.wants("wino_transform"):
             PROFILER.nbytes["wino_transform"] = PROFILER.nbytes.get("wino_transform", 0.0) + 4.0 * P * T * ((Cin if kept is None else 0) + Cout)
         if kept is None:
             call("sg_wino_input", _p(x), V, B, H, W, Cin, int(relu_in), tile, s)
-        call("sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), dU + 4 * P * Cin * Cout, B, H, W, Cout, tile, s)
+        call("sg_wino_grad_input_ups" if ups else "sg_wino_grad_input", _p(dy), Qt, _p(sample_scale), _p(db), dU + 4 * P * Cin * Cout, B, H, W, Cout, tile, s)
     with _timed("wgrad_wino", 2.0 * P * T * Cin * Cout, False, ("wino_wgrad", B, H, W, Cin, Cout, 3)):
         if PROFILER is not None and PROFILER.wants("wgrad_wino"):
             PROFILER.nbytes["wgrad_wino"] = PROFILER.nbytes.get("wgrad_wino", 0.0) + 4.0 * P * (T * (Cin + Cout) + Cin * Cout)
@@ -924,6 +934,53 @@ def _wino_wgrad(x, dy, dw, db, sample_scale, relu_in: bool) -> None:
 
 def _v2_ok(K: int, N: int, kh: int, kw: int, same: bool) -> bool:
     return USE_V2 and _low() and K % 64 == 0 and N % 64 == 0 and (same or (kh == 1 and kw == 1))
+
+
+POOL2_OUT, UPS2_IN = 16, 64
+FUSE_POOL = _os.environ.get("SG_FUSE_POOL", "1") == "1"
+
+
+def conv2d_avgpool_fwd(x, w, bias=None, relu_in=False):
+    """avg_pool2x2(conv3x3_same(relu?(x)) + bias) -> [B, H/2, W/2, Cout]: the conv2 -> tf.nn.pool(AVG) pair of a ResNetBlockDown
+    (resnet_ops.py:102-106).  Where the convolution runs in the Winograd domain with 4 x 4 tiles the output transform writes the 2 x 2
+    means of its tile directly (SG_POOL2_OUT): the full-resolution tensor -- which nothing else reads, forward or backward -- is never
+    written or re-read.  Elsewhere: the convolution, then sg_avgpool2_add_fwd."""
+    _chk(x, w, bias)
+    B, H, W, Cin = x.shape
+    kh, kw, wc, Cout = w.shape
+    if FUSE_POOL and _wino_ok(Cin, Cout, kh, kw, True, H, W, B) and _wino_tile(H, W) == 4:
+        out = empty(B, H // 2, W // 2, Cout, like=x)
+        _wino_conv(x, w, out, bias, None, None, Cin, Cout, relu_in, POOL2_OUT, ("wino_fwd", B, H, W, Cin, Cout, kh))
+        return out
+    return avgpool2_add_fwd(conv2d_fwd(x, w, bias, relu_in=relu_in))
+
+
+def pooled_grad_foldable(B: int, H: int, W: int, Cin: int, Cout: int, want_dw: bool) -> bool:
+    """May the backward of `conv3x3 -> avg_pool2x2` skip the full-resolution gradient?  Yes when the convolution's data-grad (and, if
+    wanted, its weight-grad) run in the Winograd domain with 4 x 4 tiles: both gradient transforms then read the pooled gradient."""
+    if not (FUSE_POOL and CONV_DTYPE == "f32"):
+        return False
+    if not (_wino_ok(Cout, Cin, 3, 3, True, H, W, B) and _wino_tile(H, W) == 4):
+        return False
+    if want_dw and not (_wino_wgrad_ok(Cin, Cout, 3, 3, True, H, W) and B * (H // 4) * (W // 4) >= WINO4_WGRAD_MIN_TILES):
+        return False
+    return True
+
+
+def conv2d_avgpool_bwd(x, dout, w, mask, dw=None, db=None, sample_scale=None, relu_in=True):
+    """Backward of conv2d_avgpool_fwd: dout [B,H/2,W/2,Cout] is the gradient of the POOLED output; d_c = 0.25 * upsample2x2(dout) is the
+    gradient of the convolution's output and is never materialised (UPS2_IN).  dw / db (optional) += the convolution's weight / bias
+    gradient (x = its input, relu_in as in the forward, sample_scale as in conv2d_bwd_weight); returns dx = data-grad(d_c), zeroed
+    where mask <= 0.  Callers check pooled_grad_foldable first."""
+    _chk(x, dout, w, mask, dw, db, sample_scale)
+    B, H, W, Cin = x.shape
+    Cout = dout.shape[3]
+    assert dout.shape[1] * 2 == H and dout.shape[2] * 2 == W and w.shape[2] == Cin and w.shape[3] == Cout
+    if dw is not None:
+        _wino_wgrad(x, dout, dw, db, sample_scale, relu_in, ups=True)
+    dx = empty(B, H, W, Cin, like=x)
+    _wino_conv(dout, w, dx, None, None, mask, Cout, Cin, False, 0, ("wino_dgrad", B, H, W, Cin, Cout, 3), ups=True)
+    return dx
 
 
 def conv2d_fwd(x, w, bias=None, bias2=None, same=True, relu_in=False, relu_out=False, tanh_out=False,

@@ -250,3 +250,83 @@ def test_weight_grad_reuses_the_forward_transform(dev, wino_everywhere, B, H, W,
         _close(dw, rw, 1e-5, "dW with the kept transform, " + name)
         _close(db, rb, 1e-5, "db, " + name)
     _close(y, ops.conv2d_fwd(x, w, relu_in=True), 1e-7, "forward result with V in its own tensor")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 4, 8, 128, 128), (2, 16, 80, 64, 128), (5, 8, 40, 96, 256), (2, 8, 12, 128, 64), (33, 4, 20, 256, 256)])
+def test_pooled_output_epilogue_vs_oracle(dev, B, H, W, Cin, Cout):
+    """SG_POOL2_OUT (round 4): the F(4x4) output transform writes avg_pool2x2(conv + bias) as [B, H/2, W/2, N] -- the conv2 -> AVG pool
+    pair of a ResNetBlockDown (resnet_ops.py:102-106) -- plain and accumulating; against the fp64 oracle at the forward bound 2e-5.
+    Also through ops.conv2d_avgpool_fwd, whose fallback (convolution, then the pooling kernel) must give the same tensor."""
+    from scrabble_gan_amd import ops
+    from scrabble_gan_amd._lib import call
+    g = torch.Generator(device=dev).manual_seed(B * 7 + H + Cout)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b1 = torch.randn(Cout, device=dev, generator=g)
+    ref_full = O.conv2d(torch.relu(x.double().cpu()), w.double().cpu(), b1.double().cpu())
+    ref = ref_full.reshape(B, H // 2, 2, W // 2, 2, Cout).mean(dim=(2, 4))
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN, ops.FUSE_POOL)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN = {2: 32, 4: 32}, {2: 0, 4: 0}, 0.0
+    try:
+        assert ops._wino_ok(Cin, Cout, 3, 3, True, H, W, B) and ops._wino_tile(H, W) == 4
+        ops.FUSE_POOL = True
+        fused = ops.conv2d_avgpool_fwd(x, w, b1, relu_in=True)
+        ops.FUSE_POOL = False
+        unfused = ops.conv2d_avgpool_fwd(x, w, b1, relu_in=True)
+        # the accumulating form, through the C-ABI steps: y += avg_pool(conv + bias)
+        tile, P = 4, 36
+        T = B * (H // 4) * (W // 4)
+        Tp = -(-T // 128) * 128
+        V = torch.empty(P * Tp * Cin, device=dev)
+        Mt = torch.empty(P * Tp * Cout, device=dev)
+        u = ops.packed_filter(w, "wino_fwd4")
+        prev = torch.randn(B, H // 2, W // 2, Cout, device=dev, generator=g)
+        acc = prev.clone()
+        s = ops._stream()
+        call("sg_wino_input", x.data_ptr(), V.data_ptr(), B, H, W, Cin, 1, tile, s)
+        call("sg_wino_gemm", V.data_ptr(), u.data_ptr(), Mt.data_ptr(), B, H, W, Cin, Cout, tile, s)
+        call("sg_wino_output", Mt.data_ptr(), acc.data_ptr(), b1.data_ptr(), None, None, B, H, W, Cout, ops.POOL2_OUT | ops.ACCUM, tile, s)
+        # refused combinations: F(2x2), an output ReLU, a mask
+        from scrabble_gan_amd._lib import lib
+        assert lib().sg_wino_output(Mt.data_ptr(), acc.data_ptr(), None, None, None, B, H, W, Cout, ops.POOL2_OUT | ops.RELU_OUT, tile, s) == -3
+        assert lib().sg_wino_output(Mt.data_ptr(), acc.data_ptr(), None, None, None, B, H, W, Cout, ops.POOL2_OUT, 2, s) == -3
+    finally:
+        ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN, ops.FUSE_POOL = old
+    assert fused.shape == (B, H // 2, W // 2, Cout)
+    _close(fused, ref, 2e-5, "avg_pool(conv + b), fused epilogue")
+    _close(unfused, ref, 2e-5, "avg_pool(conv + b), convolution then pooling kernel")
+    _close(acc, ref + prev.double().cpu(), 2e-5, "y += avg_pool(conv + b)")
+
+
+@pytest.mark.parametrize("B,H,W,C,scaled", [(3, 8, 16, 128, True), (2, 16, 80, 128, False), (5, 8, 40, 256, True), (33, 4, 20, 256, True)])
+def test_pooled_gradient_folded_into_the_transforms_vs_oracle(dev, B, H, W, C, scaled):
+    """SG_UPS2_IN (round 4): the backward of `conv3x3 -> avg_pool2x2` with the pooled gradient read directly by both gradient transforms --
+    d_c = 0.25 * upsample2x2(dout) is never written.  dx (ReLU-masked), dW and db (with per-sample factors and the operand ReLU) against
+    the fp64 oracle's autograd through avg_pool(conv(relu(x))), at the bounds of the unfused launches (2e-5 / 1e-4)."""
+    from scrabble_gan_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B * 11 + H + C)
+    x = torch.randn(B, H, W, C, device=dev, generator=g)
+    w = torch.randn(3, 3, C, C, device=dev, generator=g) / math.sqrt(9 * C)
+    dout = torch.randn(B, H // 2, W // 2, C, device=dev, generator=g)
+    sc = (torch.rand(B, device=dev, generator=g) * 2 - 0.5) if scaled else None
+    old = (ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN, ops.WINO4_WGRAD_MIN_TILES)
+    ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN, ops.WINO4_WGRAD_MIN_TILES = {2: 32, 4: 32}, {2: 0, 4: 0}, 0.0, 0
+    try:
+        assert ops.pooled_grad_foldable(B, H, W, C, C, True)
+        dw0, db0 = torch.randn(3, 3, C, C, device=dev, generator=g), torch.randn(C, device=dev, generator=g)
+        dw, db = dw0.clone(), db0.clone()
+        dx = ops.conv2d_avgpool_bwd(x, dout, w, x, dw=dw, db=db, sample_scale=sc, relu_in=True)
+    finally:
+        ops.WINO_MIN_C, ops.WINO_MIN_KN, ops.WINO_ROW_GAIN, ops.WINO4_WGRAD_MIN_TILES = old
+    xd = x.double().cpu().requires_grad_(True)
+    wd = w.double().cpu().requires_grad_(True)
+    bd = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    y = O.conv2d(torch.relu(xd), wd, bd).reshape(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+    dd = dout.double().cpu()
+    # the image gradient carries the plain upstream, the weight / bias gradients the per-sample factors
+    gx, = torch.autograd.grad((y * dd).sum(), xd, retain_graph=True)
+    dds = dd if sc is None else dd * sc.double().cpu().view(B, 1, 1, 1)
+    gw, gb = torch.autograd.grad((y * dds).sum(), (wd, bd))
+    _close(dx, gx, 2e-5, "dx through avg_pool and conv (masked by relu(x))")
+    _close(dw - dw0, gw, 1e-4, "dW")
+    _close(db - db0, gb, 1e-4, "db")

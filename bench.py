@@ -303,13 +303,13 @@ def roofline_of(res, conv_dtype, world):
         return PEAK_TF["f32"] if conv_dtype == "f32" else PEAK_TF["bf16"]
     dom = "igemm_fp8" if (conv_dtype == "fp8" and "igemm_fp8" in ks) else "igemm"
     if conv_dtype == "f32" and ks.get("igemm_wino", {}).get("ms", 0.0) > ks.get("igemm", {}).get("ms", 0.0):
-        dom = "igemm_wino"      # the grouped Winograd-domain products (one kernel: sg_igemm_bf16v2_kernel<128, 4, false, 128>)
+        dom = "igemm_wino"      # the grouped Winograd-domain products (one kernel template: sg_igemm_bf16v2_kernel<128 | 64, 4, false, 128, 0 | 8>)
     ig = ks.get(dom, {"tflops": 0.0, "launches": 0, "ms": 0.0})
     try:
         traffic, traffic_src = committed_traffic(dom if dom == "igemm_wino" else "igemm", conv_dtype, res["B"] // world)
     except Exception:  # noqa: BLE001
         traffic, traffic_src = None, None
-    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128> (the 36 (F(4x4,3x3)) or 16 (F(2x2,3x3)) grouped Winograd-domain products of a 3x3 conv fwd / data-grad in one launch, "
+    kernel_name = {"f32": "sg_igemm_bf16v2_kernel<128, 4, false, 128, 0 | 8> (four / eight waves per 128 x 128 tile; <64, 4, false, 128, 0> for 64 output channels): the 36 (F(4x4,3x3)) or 16 (F(2x2,3x3)) grouped Winograd-domain products of a 3x3 conv fwd / data-grad in one launch, "
                           "fp32 MFMA 32x32x2, executed FLOPs; the direct launches -- 1x1, 64-channel, strided -- are the family 'igemm')" if dom == "igemm_wino" else
                           "sg_igemm_kernel + sg_igemm_bf16v2_kernel<BN, 4, RELU> for the large-grid launches (conv fwd + data-grad, fp32 MFMA 32x32x2)",
                    "bf16": "sg_igemm_bf16v2_kernel<BN, 2, RELU> / sg_igemm_bf16_kernel (conv fwd + data-grad, bf16 MFMA 32x32x16; <= 32-filter convs stay fp32)",

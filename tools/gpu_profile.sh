@@ -33,7 +33,7 @@ python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_w
   --command "$CMD" --out $O/igemm_traffic_bs128.json > $O/traffic.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel sg_wgrad_kernel \
   --command "$CMD" --out $O/wgrad_traffic_bs128.json >> $O/traffic.log 2>&1
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel "sg_igemm_bf16v2_kernel<128, 4, false, 128>" \
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel "sg_igemm_bf16v2_kernel<128, 4, false, 128" \
   --command "$CMD" --out $O/igemm_wino_traffic_bs128.json >> $O/traffic.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch/run_counter_collection.csv $O/pmc_write/run_counter_collection.csv --kernel "sg_wgrad_kernel<128, 128, 2, 2, 16, 3, true, 0>" \
   --command "$CMD" --out $O/wgrad_wino_traffic_bs128.json >> $O/traffic.log 2>&1

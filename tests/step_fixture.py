@@ -17,26 +17,39 @@ from oracle import scrabble_oracle as O
 NL_NAMES = ("G.style", "G.up", "D.fake", "D.real", "S.fake", "S.style", "S.real")
 
 
+_WEIGHTS = {}       # (seed, logit_scale, z_scale) -> (the four networks' fp64 weights, generator state behind them): the orthogonal
+                    # initialisers (QR of up to 9216 x 1024 matrices in fp64) cost ~20 s per problem on the box's host; six tests share seed 8
+
+
 def make_problem(B=8, L_r=2, L_f=2, style_w=32, seed=8, logit_scale=300.0, z_scale=30.0):
     gen = torch.Generator().manual_seed(seed)
     dt = torch.float64
-    P = {"G": O.init_generator(gen, dt), "D": O.init_discriminator(gen, dt), "S": O.init_discriminator(gen, dt),
-         "R": O.init_recognizer(gen, dt)}
-    for n, W in P.items():
-        for k, v in W.items():
-            if k.endswith(".sigma"):
-                W[k] = torch.tensor(0.3, dtype=dt)
-            elif k.endswith(".b") or k.endswith(".beta"):
-                W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * (0.01 if n in ("D", "S") else 0.1)
-            elif k.endswith(".gamma"):
-                W[k] = 1 + torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
-            elif k.endswith(".mm"):
-                W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
-            elif k.endswith(".mv"):
-                W[k] = 1 + torch.rand(v.shape, generator=gen, dtype=dt) * 0.2
-    P["D"]["dense.w"] = P["D"]["dense.w"] * logit_scale
-    P["S"]["dense.w"] = P["S"]["dense.w"] * logit_scale
-    P["G"]["zdense.w"] = P["G"]["zdense.w"] * z_scale
+    key = (seed, float(logit_scale), float(z_scale))
+    if key in _WEIGHTS:
+        P0, state = _WEIGHTS[key]
+        P = {n: {k: v.clone() for k, v in W.items()} for n, W in P0.items()}
+        gen.set_state(state)
+    else:
+        P = {"G": O.init_generator(gen, dt), "D": O.init_discriminator(gen, dt), "S": O.init_discriminator(gen, dt),
+             "R": O.init_recognizer(gen, dt)}
+        for n, W in P.items():
+            for k, v in W.items():
+                if k.endswith(".sigma"):
+                    W[k] = torch.tensor(0.3, dtype=dt)
+                elif k.endswith(".b") or k.endswith(".beta"):
+                    W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * (0.01 if n in ("D", "S") else 0.1)
+                elif k.endswith(".gamma"):
+                    W[k] = 1 + torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
+                elif k.endswith(".mm"):
+                    W[k] = torch.randn(v.shape, generator=gen, dtype=dt) * 0.1
+                elif k.endswith(".mv"):
+                    W[k] = 1 + torch.rand(v.shape, generator=gen, dtype=dt) * 0.2
+        P["D"]["dense.w"] = P["D"]["dense.w"] * logit_scale
+        P["S"]["dense.w"] = P["S"]["dense.w"] * logit_scale
+        P["G"]["zdense.w"] = P["G"]["zdense.w"] * z_scale
+        if len(_WEIGHTS) >= 2:
+            _WEIGHTS.clear()
+        _WEIGHTS[key] = ({n: {k: v.clone() for k, v in W.items()} for n, W in P.items()}, gen.get_state())
     images = torch.rand(B, 32, 16 * L_r, 1, generator=gen, dtype=dt) * 2 - 1
     noise = torch.rand(B, 32, style_w, 1, generator=gen, dtype=dt) * 2 - 1
     style = (0.3 * noise + torch.linspace(-1, 1, B, dtype=dt).view(B, 1, 1, 1)).clamp(-1, 1)
